@@ -1,0 +1,140 @@
+"""Shared test helpers: golden-fixture loading and oracle Problem construction.
+
+The oracle (oracle/pinn_oracle.py) is test infrastructure; only tests import it.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import pinn_oracle as orc  # noqa: E402
+
+
+def load_npz(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def load_run(example):
+    with open(os.path.join(GOLDEN, f"run_{example}.json")) as f:
+        return json.load(f)
+
+
+def input_json(example):
+    return os.path.join(GOLDEN, "inputs", example + ".json")
+
+
+def theta_from(rec, prefix="theta_"):
+    out = []
+    i = 0
+    while f"{prefix}{i}" in rec:
+        out.append(np.array(rec[f"{prefix}{i}"], dtype=np.float32))
+        i += 1
+    return out
+
+
+def split_nets(theta, n_nets_tensors=6):
+    """Split a flat young->area->density tensor list into per-net lists (2 hidden layers
+    => 6 tensors per net)."""
+    return [theta[i:i + n_nets_tensors] for i in range(0, len(theta), n_nets_tensors)]
+
+
+def example_problem(example, theta=None):
+    """Oracle Problem for one of the reference's example JSONs (4-node chain).  The JSON
+    semantics restated here follow FEM/python/examples/json/generic.py:145-374."""
+    with open(input_json(example)) as f:
+        data = json.load(f)
+    nodes_list = data["nodes"]
+    nodes = np.array([[n["x"], n["y"]] for n in nodes_list])
+    elements = np.array(data["elements"])
+    fixed = []
+    for i, n in enumerate(nodes_list):
+        if n.get("fixed", False):
+            fixed += [2 * i, 2 * i + 1]
+        else:
+            if n.get("fixed_x", False):
+                fixed.append(2 * i)
+            if n.get("fixed_y", False):
+                fixed.append(2 * i + 1)
+    loads = np.array(data["loads"], dtype=float)
+    mat = data.get("material", {})
+    base = {"young": mat.get("young", 210e9), "area": mat.get("area", 0.01),
+            "density": mat.get("density", 7850)}
+    nn_cfg = data.get("nn_config", {})
+    props = {}
+    nets = split_nets(theta) if theta is not None else []
+    k = 0
+    for name in ("young", "area", "density"):
+        if nn_cfg.get(name, {}).get("enabled", False):
+            props[name] = orc.NetParams([t.copy() for t in nets[k]], scale=base[name])
+            k += 1
+        else:
+            props[name] = base[name]
+    mv = md = None
+    if data.get("solver_type", "fem").startswith("pinn"):
+        md_l, mv_l = [], []
+        m = data.get("measured_displacements")
+        if m:
+            for idx, nid in enumerate(m.get("nodes", [])):
+                if idx < len(m.get("ux", [])):
+                    md_l.append(2 * nid)
+                    mv_l.append(m["ux"][idx])
+                if idx < len(m.get("uy", [])):
+                    md_l.append(2 * nid + 1)
+                    mv_l.append(m["uy"][idx])
+        mv, md = np.array(mv_l, dtype=float), np.array(md_l, dtype=int)
+    pb = orc.Problem(nodes=nodes, elements=elements, loads=loads, fixed_dofs=np.array(fixed),
+                     dimension=2, young=props["young"], area=props["area"],
+                     density=props["density"], measured_vals=mv, measured_dofs=md)
+    pc, sc = data.get("pinn_config", {}), data.get("solver_config", {})
+    st = data.get("solver_type", "auto")
+    method = sc.get("method") or {"fem": "nr", "pinn-gd": "gd", "pinn": "gd",
+                                  "pinn-hybrid": "hybrid"}.get(st, "auto")
+    cfg = orc.SolverConfig(
+        max_iterations=pc.get("max_iterations", sc.get("max_iterations", 1000)),
+        tolerance=pc.get("tolerance", sc.get("tolerance", 1e-6)),
+        print_every=pc.get("print_every", 10),
+        n_increments=sc.get("n_increments", 10),
+        learning_rate_u=sc.get("learning_rate_u", pc.get("learning_rate_u", 1e-7)),
+        learning_rate_theta=sc.get("learning_rate_theta", pc.get("learning_rate_theta", 1e-4)),
+        alpha_physics=pc.get("alpha_physics", 1.0), alpha_data=pc.get("alpha_data", 100.0),
+        preconditioning=pc.get("preconditioning", sc.get("preconditioning", False)),
+        method=method)
+    return pb, cfg
+
+
+def mesh_problem(rec, widths, scales=None, in_dim=None):
+    """Oracle Problem from a step_* mesh fixture (nodes/elements/... stored in the npz).
+    widths: hidden width per property or None for scalar, e.g. (20, 15, 10)."""
+    theta = theta_from(rec)
+    nets = split_nets(theta)
+    scales = scales if scales is not None else (1.0, 1.0, 1.0)
+    props = []
+    k = 0
+    for w, sc in zip(widths, scales):
+        if w is None:
+            props.append(float(sc))
+        else:
+            props.append(orc.NetParams(nets[k], scale=float(sc)))
+            k += 1
+    nodes = rec["nodes"]
+    dim = 1 if nodes.ndim == 1 else 2
+    return orc.Problem(nodes=nodes, elements=rec["elements"], loads=rec["loads"],
+                       fixed_dofs=rec["fixed"], dimension=dim, young=props[0], area=props[1],
+                       density=props[2], measured_vals=rec["meas_vals"],
+                       measured_dofs=rec["meas_dofs"])
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    den = max(np.max(np.abs(b)), 1e-30)
+    return float(np.max(np.abs(a - b)) / den)
