@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — element-residual-grad evaluations per second of the PINN+GD hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--elems E] [--workload ex4|ex3]
+
+One "step" is one complete GD iteration (FEM/python/fem/solver.py:254-355) over a synthetic
+collinear 2-D truss (SURVEY.md §8(d) inputs): MLP forward for E and A at every element, element
+stiffness, assembly of f_int, residual + data loss, full backward to u and theta, Adam on both,
+BC clamp, monitors and stop test.  Default workload: BASELINE.json configs[2] — example4 shape
+(3 NNs configured, E and A evaluated, like the reference) at 10^6 elements on one GPU; with
+--gpus N every rank owns its own 10^6-element shard of one N*10^6-element bar (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_EVAL = 144.0      # algorithmic HBM bytes per element-eval (fp32)
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+F32_PEAK_TFLOPS = 157.3          # dense f32 MFMA peak = f32 vector peak (MI355X_MICROARCH.md)
+
+
+def net_flops(width: int, in_dim: int = 3) -> float:
+    """Flops of one net_backward launch per element (forward recompute + backward), SURVEY §8(d):
+    forward MACs = in*h + h*h + h, backward ~= 1.9x forward."""
+    macs = in_dim * width + width * width + width
+    return 2.0 * macs * (1.0 + 1.9)
+
+
+def build_model(n_elems: int, workload: str, seed: int = 0, x0: float = 0.0):
+    import torch
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.properties import NNProperty
+    from pinn_fem_amd.nets import SimpleNN
+    from pinn_fem_amd.plan import chain_mesh
+    nodes, elements, loads, fixed, mv, md = chain_mesh(n_elems, 1.0)
+    nodes[:, 0] += x0
+    mv = mv.copy()
+    mv[0::2] += x0
+    torch.manual_seed(seed)  # young -> area -> density, like parse_problem
+    widths = {"ex4": (20, 15, 10), "ex3": (20, None, None)}[workload]
+    props = []
+    for w in widths:
+        props.append(1.0 if w is None else NNProperty(SimpleNN(2, w, 3), input_dim=3,
+                                                      enforce_positive=True, scale=1.0))
+    model = FEMModel(nodes=nodes, elements=elements, material=Material(*props), loads=loads,
+                     fixed_dofs=fixed, dimension=2)
+    return model, mv, md, widths
+
+
+def cpu_baseline(workload: str, n_sample: int, iters: int):
+    """The oracle (numpy restatement of the reference algorithm) timed on the host cores on a bounded
+    sample of the same workload: n_sample elements x iters GD iterations."""
+    import torch
+    from oracle import pinn_oracle as orc
+    from pinn_fem_amd.nets import SimpleNN
+    from pinn_fem_amd.plan import chain_mesh
+    nodes, elements, loads, fixed, mv, md = chain_mesh(n_sample, 1.0)
+    torch.manual_seed(0)
+    widths = {"ex4": (20, 15, 10), "ex3": (20, None, None)}[workload]
+    props = []
+    for w in widths:
+        if w is None:
+            props.append(1.0)
+        else:
+            props.append(orc.NetParams([p.detach().numpy().copy() for p in SimpleNN(2, w, 3).parameters()]))
+    pb = orc.Problem(nodes=nodes, elements=elements, loads=loads, fixed_dofs=fixed, dimension=2,
+                     young=props[0], area=props[1], density=props[2], measured_vals=mv, measured_dofs=md)
+    cfg = orc.SolverConfig(max_iterations=iters, learning_rate_u=0.01,
+                           learning_rate_theta=5e-4 if workload == "ex4" else 1e-3, tolerance=0.0)
+    geo = orc.element_geometry(pb)
+    orc.solve_gd(pb, orc.SolverConfig(max_iterations=1, tolerance=0.0), 0.1, geo=geo)  # touch pages
+    t0 = time.perf_counter()
+    orc.solve_gd(pb, cfg, 0.1, geo=geo)
+    dt = time.perf_counter() - t0
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": n_sample * iters / dt, "unit": "element-evals/s", "cores": int(threads),
+            "kind": "port",
+            "sample": f"oracle/pinn_oracle.py solve_gd, {n_sample} elements x {iters} GD iterations, "
+                      f"{workload} shape, {dt:.1f} s wall, host has {os.cpu_count()} cpus"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--elems", type=int, default=1_000_000, help="elements per GPU")
+    ap.add_argument("--workload", default="ex4", choices=["ex4", "ex3"])
+    ap.add_argument("--cpu-sample", type=int, default=200_000)
+    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pinn_fem_amd import _capi
+    from pinn_fem_amd.fem.solver import SolverConfig
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_local = args.elems
+    lr_t = 5e-4 if args.workload == "ex4" else 1e-3
+    cfg = SolverConfig(max_iterations=args.warmup + args.steps + 8, tolerance=0.0, learning_rate_u=0.01,
+                       learning_rate_theta=lr_t, alpha_physics=1.0, alpha_data=100.0)
+    if world == 1:
+        from pinn_fem_amd.engine import HipEngine
+        model, mv, md, widths = build_model(n_local, args.workload)
+        eng = HipEngine(model, mv, md, device=dev)
+        eng.begin(None, 0.1, cfg, want_history=False)
+        run_warm = lambda n: eng.iterate(n)
+        run_timed = lambda n: eng.iterate_timed(n)
+    else:
+        from pinn_fem_amd.dist import ShardedChainEngine
+        widths = {"ex4": (20, 15, 10), "ex3": (20, None, None)}[args.workload]
+        eng = ShardedChainEngine(n_local, args.workload, rank, world, dev)
+        eng.begin(None, 0.1, cfg)
+        run_warm = lambda n: eng.iterate(n)
+        run_timed = lambda n: eng.iterate_timed(n)
+
+    run_warm(args.warmup)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    slot_ms = run_timed(args.steps)          # HIP events around every kernel, on the launch stream
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    st = eng.state()
+    assert st.iter == args.warmup + args.steps, (st.iter, args.warmup + args.steps)
+
+    if rank == 0:
+        total_elems = n_local * world
+        value = total_elems * args.steps / dt
+        names = _capi.KERNEL_SLOT_NAMES
+        dom = int(np.argmax(slot_ms))
+        # roofline of the dominant kernel.  The net_backward kernels are bound by f32 matrix/vector
+        # throughput (dense MLP GEMM work); the node kernels by HBM.
+        if names[dom].startswith("net_backward"):
+            w = widths[0] if names[dom].endswith("young") else widths[1]
+            ach = net_flops(w) * n_local / (slot_ms[dom] * 1e-3) / 1e12
+            roof = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / F32_PEAK_TFLOPS, "traffic": None,
+                    "avg_launch_ms": float(slot_ms[dom])}
+        else:
+            # share of the 144 B/eval the kernel is responsible for is not separable: price the
+            # whole per-eval figure against this kernel's time (upper bound on its byte rate)
+            ach = ALGO_BYTES_PER_EVAL * n_local / (slot_ms[dom] * 1e-3) / 1e9
+            roof = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": float(slot_ms[dom])}
+        it_bytes = ALGO_BYTES_PER_EVAL * value / world / 1e9
+        roof["iteration_hbm_GBs_per_gpu"] = it_bytes
+        roof["iteration_hbm_frac"] = it_bytes / HBM_PEAK_GBS
+        out = {
+            "metric": "element-residual-grad evals/sec (PINN+GD iteration: MLP fwd+bwd, stiffness, "
+                      "assembly, residual, Adam), collinear truss",
+            "value": value, "unit": "element-evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload} shape (nets {widths}, E and A evaluated), "
+                                   f"{n_local} elements per GPU, collinear 2-D truss h=1, "
+                                   f"alpha_data=100 with measurements at every node, load factor 0.1",
+                       "elements_total": total_elems, "parallelism": f"elements sharded x{world}"},
+            "kernel_ms": {n: float(m) for n, m in zip(names, slot_ms)},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.cpu_iters)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,217 @@
+/*
+ * pinnfem_hip.h — C ABI of libpinnfem_hip.so (gfx950 / MI355X).
+ *
+ * The library is the hand-written HIP implementation of ONE path of the reference
+ * (rpacheco-blazquez/PINN-FEM): the body of the PINN+GD iteration
+ *     assemble_system_torch -> residual/loss -> loss.backward() -> Adam(u), Adam(theta)
+ *     -> BC clamp -> monitors/stop test          (FEM/python/fem/solver.py:252-355)
+ * The reference has no native code and no FFI; every entry point below names the Python
+ * lines it replaces.  A Python binding (ctypes) is in pinn_fem_amd/_capi.py and the stub a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every pointer marked "dev" is a DEVICE pointer owned by the caller
+ *     (PyTorch's allocator in our host code); the library allocates nothing and keeps no
+ *     state between calls, so every call is re-entrant and graph-capturable;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work (no sync);
+ *   - return value: 0 = ok, <0 = error (see pf_last_error()); no exceptions cross the ABI;
+ *   - all floating point is IEEE float32 unless a field says double.
+ */
+#ifndef PINNFEM_HIP_H
+#define PINNFEM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_ABI_VERSION 1
+
+/* error codes */
+#define PF_OK 0
+#define PF_ERR_ARG (-1)          /* bad argument / inconsistent sizes */
+#define PF_ERR_UNSUPPORTED (-2)  /* net shape outside the compiled menu */
+#define PF_ERR_HIP (-3)          /* a HIP runtime call failed */
+
+/* dof flag bits (pf_mesh.dof_flags) */
+#define PF_DOF_FIXED 1u
+#define PF_DOF_MEASURED 2u
+
+/* weight-gradient reduction engines for pf_net_backward */
+#define PF_WG_SHUFFLE 0 /* wave shuffles, VALU only (slow, simple) */
+#define PF_WG_MFMA 1    /* v_mfma_f32_16x16x4_f32 over LDS-transposed tiles */
+
+/* element-force formulations */
+#define PF_FE_REFERENCE 0 /* 4-term dot per row, the reference's order (nn_assembly.py:96-100) */
+#define PF_FE_DELTA 1     /* on d = u_j - u_i: same algebra, no float32 cancellation (opt-in) */
+
+/* Mesh-derived immutable data ("plan").  Replaces the per-iteration Python work of
+ * fem/nn_assembly.py:181-205 (dof numbering, centroid, direction cosines) and
+ * fem/boundary.py:8-13 (free/fixed partition).  All arrays dev. */
+typedef struct pf_mesh {
+  int32_t dim;             /* 1 (nn_assembly.py:129-179) or 2 (:181-229) */
+  int32_t n_nodes;
+  int32_t n_elems;
+  int32_t n_dofs;          /* n_nodes*dim */
+  const int32_t* conn;     /* [n_elems][2] node ids (i,j) */
+  const float* egeo;       /* [n_elems][4] = c2, cs, s2, l0  (float32 of the float64 values the
+                              reference computes, nn_assembly.py:64-82; 1-D: 1,0,0,|dx|) */
+  const float* ecent;      /* [n_elems][dim] centroid = NN input columns after load_factor */
+  const int32_t* adj_ptr;  /* [n_nodes+1] CSR node -> incident elements, ascending element id */
+  const int32_t* adj;      /* [adj_ptr[n_nodes]] entries (elem<<1)|end, end=0: node is i */
+  const float* f_ext;      /* [n_dofs] external loads (solver.py:218) */
+  const uint8_t* dof_flags;/* [n_dofs] PF_DOF_* */
+  const float* meas_val;   /* [n_dofs] measured displacement where PF_DOF_MEASURED */
+  int32_t n_meas;          /* number of measurements m (denominator of the mean, solver.py:275) */
+  int32_t _pad;
+} pf_mesh;
+
+/* One material property: constant, or MLP(load_factor, x[, y]) -> softplus -> *scale
+ * (fem/properties.py:97-161, examples/json/generic.py:118-142). */
+typedef struct pf_net {
+  int32_t enabled;     /* 0: constant property = scale */
+  int32_t in_dim;      /* must be mesh.dim+1: columns [load_factor, x(, y)] (properties.py:119) */
+  int32_t width;       /* hidden width h (1..32) */
+  int32_t n_hidden;    /* hidden layers (1..3) */
+  int32_t positive;    /* softplus on the output (enforce_positive) */
+  float scale;         /* output scale = base property value */
+  int32_t theta_off;   /* offset of this net's first parameter in the flat theta vector */
+  int32_t pad_off;     /* offset of this net in the padded-parameter workspace */
+} pf_net;
+
+/* Device-resident iteration state; written only by kernels.  One per solve_gd call. */
+typedef struct pf_state {
+  int32_t iter;        /* completed iterations (= Adam step count) */
+  int32_t done;        /* 1 once the stop test fired (solver.py:341-355); later launches no-op */
+  int32_t converged;   /* same as done (kept separate for max_iterations exits) */
+  int32_t _pad;
+  /* Adam scalars for the NEXT step, computed in double like torch does on the host */
+  float step_size_u, step_size_t, bc2_sqrt, _pad2;
+  /* last iteration's monitors (solver.py:304-320) */
+  float loss_total, loss_physics, loss_data, u_norm, residual_norm, theta_norm;
+  float _pad3[2];
+} pf_state;
+
+#define PF_HIST_COLS 6 /* loss_total, loss_physics, loss_data, u_norm, residual_norm, theta_norm */
+
+/* Everything one GD iteration touches.  Filled by the host once per solve_gd call. */
+typedef struct pf_problem {
+  pf_mesh mesh;
+  pf_net net[2];           /* 0: young, 1: area (density is never evaluated, nn_assembly.py:207) */
+  /* unknowns + Adam moments (solver.py:205-216, 234-236); all dev */
+  float* u;                /* [n_dofs] */
+  float* m_u;
+  float* v_u;
+  float* theta;            /* [n_theta] flat, torch parameters() order young->area->density */
+  float* m_t;
+  float* v_t;
+  int32_t n_theta;         /* all parameters incl. density net */
+  int32_t n_theta_active;  /* leading parameters that receive gradients (young+area nets) */
+  const int32_t* tensor_off; /* dev [n_tensors+1] parameter-tensor boundaries for theta_norm */
+  int32_t n_tensors;
+  int32_t wg_mode;         /* PF_WG_* */
+  /* scalars of SolverConfig (solver.py:35-62) */
+  float lam;               /* load factor of this increment */
+  float alpha_physics, alpha_data;
+  float lr_u, lr_t;
+  double tol;
+  double beta1, beta2, eps;
+  int32_t use_data;        /* has_measurements && alpha_data>0 (solver.py:273) */
+  int32_t max_iter;
+  /* workspaces, all dev, sizes from pf_workspace_sizes() */
+  float* theta_pad;        /* padded parameter image the net kernels read */
+  float* prop_e;           /* [n_elems] young per element */
+  float* prop_a;           /* [n_elems] area per element */
+  float* g_f;              /* [n_dofs] dL/df_int (alpha_p*r on free dofs, 0 on fixed) */
+  float* g_ea;             /* [n_elems] dL/d(E*A) per element */
+  float* grad_u;           /* [n_dofs] or NULL (only needed by the autograd binding) */
+  float* grad_theta;       /* [n_theta] reduced parameter gradient */
+  float* partials;         /* block partial sums (scalars + padded weight gradients) */
+  float* hist;             /* [max_iter][PF_HIST_COLS] per-iteration monitors */
+  pf_state* state;
+  int32_t n_part_blocks;   /* grid size used for partial sums (host picks, <= PF_MAX_BLOCKS) */
+  int32_t pad_total;       /* floats of the padded-parameter image of all active nets */
+  const int32_t* pad_index;/* dev [n_theta_active] torch-layout index -> padded-image index */
+  float n_meas_f;          /* (float)mesh.n_meas */
+  int32_t fe_mode;         /* PF_FE_* : how fe = ke @ u_e is evaluated */
+} pf_problem;
+
+#define PF_MAX_BLOCKS 1024
+
+/* ---- introspection ------------------------------------------------------------------ */
+int pf_abi_version(void);
+const char* pf_last_error(void);
+/* number of parameters of an MLP in torch parameters() order (generic.py:121-134) */
+int pf_net_param_count(int in_dim, int width, int n_hidden);
+/* padded width the kernels use for `width`, or PF_ERR_UNSUPPORTED */
+int pf_padded_width(int width);
+/* floats of padded-parameter workspace one net needs, or <0 */
+int pf_net_pad_count(int in_dim, int width, int n_hidden);
+/* padded-image index (inside the net's image) of the net's `local`-th torch parameter */
+int pf_net_pad_index(int in_dim, int width, int n_hidden, int local);
+/* sizeof of the ABI structs: 0 pf_mesh, 1 pf_net, 2 pf_state, 3 pf_problem (binding self-check) */
+int pf_sizeof(int what);
+/* floats needed in pf_problem.partials for the given block count */
+long long pf_partials_count(const pf_problem* p);
+
+/* ---- building blocks (each replaces the cited reference lines) ------------------------ */
+/* torch-layout theta -> padded image (no reference analogue; internal layout change) */
+int pf_pack_theta(const pf_problem* p, void* stream);
+/* NNProperty.value for every element: properties.py:116-161 + generic.py:141 (batch of n_elems
+ * instead of n_elems batch-1 calls).  which: 0 young, 1 area.  Output p->prop_e / prop_a. */
+int pf_net_forward(const pf_problem* p, int which, void* stream);
+/* f_int = K(theta) u by node-wise gather of fe = (s*pattern) @ u_elem:
+ * nn_assembly.py:64-100 + 226-227 (f_int only; K is never formed).  f_int_out dev [n_dofs]. */
+int pf_internal_force(const pf_problem* p, const float* u, float* f_int_out, void* stream);
+/* residual + losses + dL/df_int: solver.py:267-283.  Fuses pf_internal_force.  Writes p->g_f and
+ * block partials of sum r^2, sum d^2; f_int_out may be NULL. */
+int pf_node_residual(const pf_problem* p, float* f_int_out, void* stream);
+/* per-element dL/d(EA): the part of loss.backward() (solver.py:289) through ke = s*pattern,
+ * fe = ke@u (nn_assembly.py:96-100).  Writes p->g_ea. */
+int pf_elem_adjoint(const pf_problem* p, void* stream);
+/* backward of NNProperty.value for every element + reduction over elements of the parameter
+ * gradient (autograd of properties.py:150-156 / generic.py:141).  Writes block partials. */
+int pf_net_backward(const pf_problem* p, int which, void* stream);
+/* dL/du by node-wise gather (K^T g_f) + data term (solver.py:273-279 backward).
+ * fuse_adam!=0: also optimizer_u.step() + u[fixed]=0 (solver.py:292, 297-298) in the same pass
+ * and block partials of ||u_free||^2 (solver.py:304). */
+int pf_node_gradu(const pf_problem* p, int fuse_adam, void* stream);
+/* sum the parameter-gradient partials in fixed order -> p->grad_theta; fuse_adam!=0: also
+ * optimizer_theta.step() (solver.py:293-294) and refresh of the padded image. */
+int pf_theta_reduce(const pf_problem* p, int fuse_adam, void* stream);
+/* monitors, history row, stop test, Adam scalars of the next step: solver.py:304-355. */
+int pf_finalize(const pf_problem* p, void* stream);
+/* reset state for a new solve_gd call (fresh Adam: solver.py:234-238): zero moments, iter=0 */
+int pf_reset(const pf_problem* p, void* stream);
+
+/* ---- the fused loop ------------------------------------------------------------------- */
+/* Enqueue n_iter complete GD iterations (solver.py:254-355).  Once the device-side stop test
+ * fires, remaining launches are no-ops, so the final state equals the reference's `break`. */
+int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream);
+/* Profiling twin of pf_gd_iterations: same launches with a HIP event before every kernel slot, then
+ * a stream synchronise; ms_per_kernel (HOST, PF_KERNEL_SLOTS floats) receives the average duration
+ * of each slot: 0 net_forward(young) 1 net_forward(area) 2 node_residual 3 elem_adjoint
+ * 4 net_backward(young) 5 net_backward(area) 6 node_gradu+Adam 7 theta_reduce+Adam 8 finalize. */
+#define PF_KERNEL_SLOTS 9
+int pf_gd_iterations_timed(const pf_problem* p, int n_iter, void* stream, float* ms_per_kernel);
+/* loss and gradients only (no optimiser): what torch.autograd.Function.forward/backward need.
+ * Requires p->grad_u != NULL.  Leaves loss terms in p->state, gradients in grad_u/grad_theta. */
+int pf_loss_and_grads(const pf_problem* p, void* stream);
+
+/* ---- extensions (off the default path) ------------------------------------------------ */
+/* generic Adam (torch.optim.Adam single-tensor arithmetic) on a flat vector */
+int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step,
+            double lr, double beta1, double beta2, double eps, void* stream);
+/* diag(K(theta)) [n_dofs] — the Jacobi preconditioner the north-star names; the reference has
+ * no such preconditioner (solver.py:113-195 is a two-phase schedule), so nothing calls this
+ * by default.  Uses p->prop_e/prop_a from the last pf_net_forward. */
+int pf_diag_k(const pf_problem* p, float* diag_out, void* stream);
+/* dense k_global [n_dofs][n_dofs] row-major, for assemble_system_torch's return value
+ * (nn_assembly.py:228-231); small n_dofs only (<= 4096). */
+int pf_dense_k(const pf_problem* p, float* k_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINNFEM_HIP_H */

@@ -227,15 +227,35 @@ def element_stiffness(pb: Problem, geo: Geometry, lam: float):
     return s, e_val, a_val, e_ctx, a_ctx
 
 
-def internal_force(geo: Geometry, s: np.ndarray, u: np.ndarray, ndof: int) -> np.ndarray:
+def ke_times(geo: Geometry, s: np.ndarray, ve: np.ndarray, fe_mode: str = "reference") -> np.ndarray:
+    """(s*pattern) @ v_elem for every element, v_elem = ve[e] (nelm, nd).
+    "reference": ke = s*pattern, then a 4-term dot per row, b ascending (nn_assembly.py:96-100).
+    "delta": the same product written on d = v_j - v_i (mathematically identical; avoids the
+    float32 cancellation of the reference order on long chains; opt-in extension)."""
+    nd = geo.dofs.shape[1]
+    if fe_mode == "delta":
+        h = nd // 2
+        d = (ve[:, h:] - ve[:, :h]).astype(f32)
+        q = np.zeros((len(s), h), dtype=f32)
+        for a in range(h):
+            acc = (geo.pattern[:, a, 0] * d[:, 0]).astype(f32)
+            for b in range(1, h):
+                acc = (acc + geo.pattern[:, a, b] * d[:, b]).astype(f32)
+            q[:, a] = acc
+        sq = (s[:, None] * q).astype(f32)
+        return np.concatenate([-sq, sq], axis=1).astype(f32)
+    ke = (s[:, None, None] * geo.pattern).astype(f32)
+    out = np.zeros((len(s), nd), dtype=f32)
+    for b in range(nd):                                    # 4-term dot, b ascending
+        out = (out + ke[:, :, b] * ve[:, b:b + 1]).astype(f32)
+    return out
+
+
+def internal_force(geo: Geometry, s: np.ndarray, u: np.ndarray, ndof: int,
+                   fe_mode: str = "reference") -> np.ndarray:
     """fe = (s*pattern) @ u_elem, then f_int[g] += fe[a] in element order
     (nn_assembly.py:96-100, :226-227)."""
-    ke = (s[:, None, None] * geo.pattern).astype(f32)
-    ue = u.astype(f32)[geo.dofs]
-    nd = geo.dofs.shape[1]
-    fe = np.zeros((len(s), nd), dtype=f32)
-    for b in range(nd):                                    # 4-term dot, b ascending
-        fe = (fe + ke[:, :, b] * ue[:, b:b + 1]).astype(f32)
+    fe = ke_times(geo, s, u.astype(f32)[geo.dofs], fe_mode)
     f_int = np.zeros(ndof, dtype=f32)
     np.add.at(f_int, geo.dofs.reshape(-1), fe.reshape(-1))  # sequential, element order
     return f_int
@@ -243,12 +263,12 @@ def internal_force(geo: Geometry, s: np.ndarray, u: np.ndarray, ndof: int) -> np
 
 def loss_and_grads(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
                    alpha_physics: float = 1.0, alpha_data: float = 100.0,
-                   want_grads: bool = True) -> StepOut:
+                   want_grads: bool = True, fe_mode: str = "reference") -> StepOut:
     u = u.astype(f32)
     ndof = pb.ndof
     free, fixed = free_and_fixed_dofs(ndof, pb.fixed_dofs)
     s, e_val, a_val, e_ctx, a_ctx = element_stiffness(pb, geo, lam)
-    f_int = internal_force(geo, s, u, ndof)
+    f_int = internal_force(geo, s, u, ndof, fe_mode)
     f_ext = pb.loads.astype(f32)
     r = (f_int[free] - f32(lam) * f_ext[free]).astype(f32)         # solver.py:267-269
     loss_p = f32(0.5) * np.sum(r * r, dtype=f32)                    # :270
@@ -270,21 +290,14 @@ def loss_and_grads(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
         g_f = np.zeros(ndof, dtype=f32)
         g_f[free] = (f32(alpha_physics) * r).astype(f32)            # dL/df_int (free rows only)
         g_fe = g_f[geo.dofs]                                        # (nelm, nd)
-        ke = (s[:, None, None] * geo.pattern).astype(f32)
-        nd = geo.dofs.shape[1]
-        # grad_u[dof_b] += sum_a g_fe[a]*ke[a][b]
-        gue = np.zeros((len(s), nd), dtype=f32)
-        for a in range(nd):
-            gue = (gue + g_fe[:, a:a + 1] * ke[:, a, :]).astype(f32)
+        # grad_u[dof_b] += sum_a g_fe[a]*ke[a][b]   (ke symmetric: the same operator applied to g_fe)
+        gue = ke_times(geo, s, g_fe, fe_mode)
         np.add.at(grad_u, geo.dofs.reshape(-1), gue.reshape(-1))
         if use_data:
             g_d = (f32(alpha_data) / f32(len(mv))) * (f32(2.0) * d)
             np.add.at(grad_u, md, (-g_d).astype(f32))
         # g_s = sum_ab g_fe[a]*pattern[a][b]*u[b]
-        ue = u[geo.dofs]
-        pu = np.zeros((len(s), nd), dtype=f32)
-        for b in range(nd):
-            pu = (pu + geo.pattern[:, :, b] * ue[:, b:b + 1]).astype(f32)
+        pu = ke_times(geo, np.ones_like(s), u[geo.dofs], fe_mode)
         g_s = np.sum(g_fe * pu, axis=1, dtype=f32)
         g_ea = (g_s / geo.l0).astype(f32)
         for prop, ctx, other in ((pb.young, e_ctx, a_val), (pb.area, a_ctx, e_val)):
@@ -394,7 +407,7 @@ class SolverResult:
 def solve_gd(pb: Problem, config: Optional[SolverConfig] = None,
              target_load_factor: float = 1.0, u_initial: Optional[np.ndarray] = None,
              skip_preconditioning: bool = False, geo: Optional[Geometry] = None,
-             call_log: Optional[list] = None) -> SolverResult:
+             call_log: Optional[list] = None, fe_mode: str = "reference") -> SolverResult:
     """fem/solver.py:83-400.  Measurements travel inside `pb`."""
     config = config or SolverConfig()
     geo = geo or element_geometry(pb)
@@ -404,14 +417,14 @@ def solve_gd(pb: Problem, config: Optional[SolverConfig] = None,
         pre.max_iterations = min(300, config.max_iterations // 3)
         pre.tolerance = max(1e-4, config.tolerance * 10)
         pre.preconditioning = False
-        pre_res = solve_gd(pb, pre, target_load_factor, u_initial, True, geo, call_log)
+        pre_res = solve_gd(pb, pre, target_load_factor, u_initial, True, geo, call_log, fe_mode)
         if pre_res.converged and pre_res.history[-1].get("residual_norm", 1.0) < config.tolerance:
             return pre_res
         main = copy.deepcopy(config)
         main.max_iterations = config.max_iterations - pre.max_iterations
         main.preconditioning = False
         main_res = solve_gd(pb, main, target_load_factor,
-                            pre_res.displacements.flatten().astype(f32), True, geo, call_log)
+                            pre_res.displacements.flatten().astype(f32), True, geo, call_log, fe_mode)
         off = pre_res.history[-1].get("iteration", 0) if pre_res.history else 0
         merged = list(pre_res.history)
         for h in main_res.history:
@@ -433,7 +446,8 @@ def solve_gd(pb: Problem, config: Optional[SolverConfig] = None,
     converged = False
     lam = target_load_factor
     for it in range(config.max_iterations):                            # :252
-        st = loss_and_grads(pb, geo, u, lam, config.alpha_physics, config.alpha_data)
+        st = loss_and_grads(pb, geo, u, lam, config.alpha_physics, config.alpha_data,
+                            fe_mode=fe_mode)
         opt_u.update([u], [st.grad_u])                                 # :292
         if opt_t is not None:
             opt_t.update(theta, st.grad_theta)                         # :294
@@ -456,7 +470,7 @@ def solve_gd(pb: Problem, config: Optional[SolverConfig] = None,
                 break
     # reactions from a re-assembly  (:374-385)
     s, *_ = element_stiffness(pb, geo, lam)
-    f_int = internal_force(geo, s, u, ndof)
+    f_int = internal_force(geo, s, u, ndof, fe_mode)
     reac = (f_int - f32(lam) * pb.loads.astype(f32)).astype(f32)
     reac[free] = f32(0.0)
     shape = (-1, 1) if pb.dimension == 1 else (pb.nnode, pb.dimension)
@@ -473,7 +487,8 @@ def solve_gd(pb: Problem, config: Optional[SolverConfig] = None,
 
 def solve_hybrid(pb: Problem, config: Optional[SolverConfig] = None,
                  target_load_factor: float = 1.0, u_initial: Optional[np.ndarray] = None,
-                 geo: Optional[Geometry] = None, call_log: Optional[list] = None) -> SolverResult:
+                 geo: Optional[Geometry] = None, call_log: Optional[list] = None,
+                 fe_mode: str = "reference") -> SolverResult:
     """fem/solver.py:520-651 — NN branch only (phase 2 is GD again when NNs are present)."""
     config = config or SolverConfig()
     geo = geo or element_geometry(pb)
@@ -483,7 +498,7 @@ def solve_hybrid(pb: Problem, config: Optional[SolverConfig] = None,
         gd_cfg = copy.deepcopy(config)
         gd_cfg.max_iterations = min(300, config.max_iterations // 3)
         gd_cfg.tolerance = max(1e-4, config.tolerance * 10)
-        gd_res = solve_gd(pb, gd_cfg, target_load_factor, u_initial, True, geo, call_log)
+        gd_res = solve_gd(pb, gd_cfg, target_load_factor, u_initial, True, geo, call_log, fe_mode)
         if gd_res.converged and gd_res.history[-1].get("residual_norm", 1.0) < config.tolerance:
             return gd_res
     if not pb.has_nn():
@@ -491,7 +506,7 @@ def solve_hybrid(pb: Problem, config: Optional[SolverConfig] = None,
     fin = copy.deepcopy(config)                                        # :600-604
     fin.max_iterations = config.max_iterations - (gd_cfg.max_iterations if gd_res else 0)
     u_warm = gd_res.displacements.flatten().astype(f32) if gd_res else u_initial
-    final = solve_gd(pb, fin, target_load_factor, u_warm, True, geo, call_log)
+    final = solve_gd(pb, fin, target_load_factor, u_warm, True, geo, call_log, fe_mode)
     if gd_res:                                                         # :623-645
         off = gd_res.history[-1].get("iteration", 0) if gd_res.history else 0
         merged = list(gd_res.history)
@@ -504,7 +519,7 @@ def solve_hybrid(pb: Problem, config: Optional[SolverConfig] = None,
 
 
 def solve(pb: Problem, config: Optional[SolverConfig] = None,
-          call_log: Optional[list] = None) -> SolverResult:
+          call_log: Optional[list] = None, fe_mode: str = "reference") -> SolverResult:
     """fem/solver.py:1045-1167 (methods gd / hybrid; 'auto' resolves to gd here because the
     NR branch is out of scope)."""
     config = config or SolverConfig()
@@ -517,9 +532,9 @@ def solve(pb: Problem, config: Optional[SolverConfig] = None,
             config.load_factor_final - config.load_factor_initial)      # :1096-1098
         u0 = None if u_cur is None else np.asarray(u_cur, dtype=f32)
         if method == "gd":
-            result = solve_gd(pb, config, lam, u0, False, geo, call_log)
+            result = solve_gd(pb, config, lam, u0, False, geo, call_log, fe_mode)
         elif method == "hybrid":
-            result = solve_hybrid(pb, config, lam, u0, geo, call_log)
+            result = solve_hybrid(pb, config, lam, u0, geo, call_log, fe_mode)
         else:
             raise ValueError(f"Unknown solver method: {method}")
         u_cur = result.displacements.flatten()

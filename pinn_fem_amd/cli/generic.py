@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Generic JSON entry point — drop-in for the reference's
+FEM/python/examples/json/generic.py (`python generic.py problem.json [output.json]`).
+
+Same input keys, same precedence rules, same output schema, same file placement
+(<stem>.log and <stem>.res.json next to the input, exit code 1 on any exception):
+  setup_logging :67   parse_problem :145   solve_problem :447   extract_nn_properties :498   main :802
+The solve itself runs through pinn_fem_amd.fem.solver (HIP kernels).
+"""
+from __future__ import annotations
+
+import json
+import logging
+import sys
+from datetime import datetime
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from ..fem.model import FEMModel, Material
+from ..fem.properties import NNProperty
+from ..fem.solver import SolverConfig, solve
+from ..nets import SimpleNN
+
+logger = None
+
+
+def setup_logging(problem_file):
+    """generic.py:67-99: <stem>.log next to the input (mode 'w'), DEBUG level, file + stdout."""
+    global logger
+    log_file = Path(problem_file).parent / f"{Path(problem_file).stem}.log"
+    logging.basicConfig(
+        level=logging.DEBUG, format="%(asctime)s [%(levelname)s] %(message)s",
+        handlers=[logging.FileHandler(log_file, mode="w", encoding="utf-8"),
+                  logging.StreamHandler(sys.stdout)], force=True)
+    logger = logging.getLogger(__name__)
+    logger.info("=" * 60)
+    logger.info("PINN-FEM Generic Solver Log")
+    logger.info(f"Timestamp: {datetime.now().strftime('%Y-%m-%d %H:%M:%S')}")
+    logger.info(f"Problem file: {problem_file}")
+    logger.info(f"Log file: {log_file}")
+    logger.info("=" * 60)
+    return log_file
+
+
+def log_print(msg="", level="info"):
+    if logger:
+        getattr(logger, level if level in ("debug", "warning", "error") else "info")(msg)
+    else:
+        print(msg)
+
+
+def _make_property(name, nn_config, base_value):
+    """generic.py:233-312: NNProperty(scale=base, enforce_positive=True) when enabled."""
+    arch = nn_config.get(name, {})
+    if not arch.get("enabled", False):
+        log_print(f"[DEBUG] {name.capitalize()}: Scalar ({base_value})", level="debug")
+        return base_value
+    input_dim = arch.get("input_dim", 1)
+    net = SimpleNN(
+        hidden_layers=arch.get("hidden_layers", arch.get("hiddenLayers", 2)),
+        neurons_per_layer=arch.get("neurons_per_layer", arch.get("neuronsPerLayer", 20)),
+        input_dim=input_dim)
+    log_print(f"[DEBUG] {name.capitalize()}: NNProperty (scale={base_value}, input_dim={input_dim})",
+              level="debug")
+    return NNProperty(net=net, input_dim=input_dim, enforce_positive=True, scale=base_value)
+
+
+def parse_problem(problem_file):
+    """JSON -> FEMModel + SolverConfig + measurements (generic.py:145-444)."""
+    log_print("\n[DEBUG] Starting parse_problem...", level="debug")
+    with open(problem_file, "r") as f:
+        data = json.load(f)
+
+    nodes_list = data.get("nodes", [])
+    if nodes_list and isinstance(nodes_list[0], list):           # :155-164
+        nodes_array = np.array(nodes_list, dtype=float)
+        problem_dim = nodes_array.shape[1]
+        nodes = nodes_array.flatten() if problem_dim == 1 else nodes_array
+    else:                                                        # :166-168
+        nodes = np.array([[n["x"], n["y"]] for n in nodes_list])
+        problem_dim = 2
+    n_nodes = len(nodes_list) if nodes_list else 0
+    n_dofs = n_nodes * problem_dim
+    log_print(f"[DEBUG] Nodes: {n_nodes}, DOFs: {n_dofs}", level="debug")
+
+    elements_data = data.get("elements", [])                     # :177-183
+    if elements_data and isinstance(elements_data[0], list):
+        elements = np.array(elements_data)
+    else:
+        elements = np.array([[e["nodes"][0], e["nodes"][1]] for e in elements_data])
+    log_print(f"[DEBUG] Elements: {len(elements)}", level="debug")
+
+    fixed_dofs_list = data.get("fixed_dofs", [])                 # :189-205
+    if fixed_dofs_list:
+        fixed_dofs = np.array(fixed_dofs_list, dtype=int)
+    else:
+        fixed = []
+        if nodes_list and isinstance(nodes_list[0], dict):
+            for i, node in enumerate(nodes_list):
+                if node.get("fixed", False):
+                    fixed.extend([2 * i, 2 * i + 1])
+                else:
+                    if node.get("fixed_x", False):
+                        fixed.append(2 * i)
+                    if node.get("fixed_y", False):
+                        fixed.append(2 * i + 1)
+        fixed_dofs = np.array(fixed, dtype=int)
+    log_print(f"[DEBUG] Fixed DOFs: {fixed_dofs}", level="debug")
+
+    f_ext = np.array(data.get("loads", [0.0] * n_dofs), dtype=float)   # :210-211
+
+    material_data = data.get("material", {})                     # :216-219
+    base = {"young": material_data.get("young", 210e9), "area": material_data.get("area", 0.01),
+            "density": material_data.get("density", 7850)}
+    nn_config = data.get("nn_config", {})
+    solver_type = data.get("solver_type", "fem")
+    # construction order young -> area -> density fixes the RNG consumption order
+    material = Material(young=_make_property("young", nn_config, base["young"]),
+                        area=_make_property("area", nn_config, base["area"]),
+                        density=_make_property("density", nn_config, base["density"]))
+
+    measured_data = {}
+    if solver_type.startswith("pinn"):                           # :320-362
+        measured_dofs, measured_values = [], []
+        md = data.get("measured_displacements", None)
+        if md:
+            if "global_dof" in md and "measured_u" in md:
+                measured_dofs, measured_values = md["global_dof"], md["measured_u"]
+            else:
+                ux, uy = md.get("ux", []), md.get("uy", [])
+                for idx, node_id in enumerate(md.get("nodes", [])):
+                    if idx < len(ux):
+                        measured_dofs.append(2 * node_id)
+                        measured_values.append(ux[idx])
+                    if idx < len(uy):
+                        measured_dofs.append(2 * node_id + 1)
+                        measured_values.append(uy[idx])
+        else:
+            for i, node in enumerate(nodes_list):
+                if not isinstance(node, dict):
+                    raise AttributeError("'list' object has no attribute 'get'")  # as the reference
+                ux_m, uy_m = node.get("measured_ux", 0), node.get("measured_uy", 0)
+                if ux_m != 0:
+                    measured_dofs.append(2 * i)
+                    measured_values.append(ux_m)
+                if uy_m != 0:
+                    measured_dofs.append(2 * i + 1)
+                    measured_values.append(uy_m)
+        measured_data = {"dofs": np.array(measured_dofs, dtype=int),
+                         "values": np.array(measured_values)}
+
+    model = FEMModel(nodes=nodes, elements=elements, material=material, loads=f_ext,
+                     fixed_dofs=fixed_dofs, dimension=problem_dim)
+
+    sc, pc = data.get("solver_config", {}), data.get("pinn_config", {})   # :377-428
+    solver_type = data.get("solver_type", "auto")
+    explicit = sc.get("method", None)
+    if explicit:
+        method = explicit
+    elif solver_type == "fem":
+        method = "nr"
+    elif solver_type in ["pinn-gd", "pinn"]:
+        method = "gd"
+    elif solver_type == "pinn-hybrid":
+        method = "hybrid"
+    else:
+        method = "auto"
+    solver_config = SolverConfig(
+        max_iterations=pc.get("max_iterations", sc.get("max_iterations", 1000)),
+        tolerance=pc.get("tolerance", sc.get("tolerance", 1e-6)),
+        print_every=pc.get("print_every", 10),
+        n_increments=sc.get("n_increments", 10),
+        min_denominator=sc.get("min_denominator", 1e-10),
+        learning_rate_u=sc.get("learning_rate_u", pc.get("learning_rate_u", 1e-7)),
+        learning_rate_theta=sc.get("learning_rate_theta", pc.get("learning_rate_theta", 1e-4)),
+        alpha_physics=pc.get("alpha_physics", 1.0),
+        alpha_data=pc.get("alpha_data", 100.0),
+        preconditioning=pc.get("preconditioning", sc.get("preconditioning", False)),
+        method=method)
+    log_print(f"[DEBUG] Solver config: method={solver_config.method}, tol={solver_config.tolerance}, "
+              f"max_iter={solver_config.max_iterations}", level="debug")
+    log_print("[DEBUG] parse_problem completed successfully", level="debug")
+    return {"model": model, "solver_config": solver_config, "measured_data": measured_data}
+
+
+def _eval_points(prop: NNProperty, pts: np.ndarray, lf, dimension: int) -> list:
+    """Batched NNProperty evaluation at points (rows of x[, y]) — replaces the reference's
+    per-point batch-1 loop (generic.py:545-581) with one device batch per point set."""
+    pts = np.asarray(pts, dtype=float).reshape(len(pts), -1)
+    cols = []
+    if lf is not None:
+        cols.append(np.full((len(pts), 1), lf))
+    cols.append(pts[:, :1])
+    if dimension >= 2:
+        cols.append(pts[:, 1:2])
+    x = np.column_stack(cols)
+    dev = next(prop.net.parameters()).device
+    with torch.no_grad():
+        out = prop.net(torch.tensor(x, dtype=torch.float32, device=dev))
+        if prop.enforce_positive:
+            out = torch.nn.functional.softplus(out)
+        out = out * prop.scale
+    return [float(v) for v in out.reshape(-1).cpu().numpy()]
+
+
+def extract_nn_properties(model, load_factors=None):
+    """Identified properties at nodes and element centroids (generic.py:498-799)."""
+    if load_factors is None:
+        load_factors = [0.2, 0.5, 1.0]
+    node_coords = model.nodes
+    centroids = (node_coords[model.elements[:, 0]] + node_coords[model.elements[:, 1]]) / 2.0
+    properties = {}
+    for name in ("young", "area", "density"):
+        prop = getattr(model.material, name)
+        if not hasattr(prop, "net"):
+            properties[name] = {"value": float(prop.value()), "type": "scalar"}
+            continue
+        cent_list = [c.tolist() for c in centroids]
+        if prop.input_dim > model.dimension:
+            variations = {}
+            for lf in load_factors:
+                variations[f"load_factor_{lf:.1f}"] = {
+                    "at_nodes": {"coords": node_coords.tolist(),
+                                 "values": _eval_points(prop, node_coords, lf, model.dimension)},
+                    "at_elements": {"centroids": cent_list,
+                                    "values": _eval_points(prop, centroids, lf, model.dimension)},
+                }
+            properties[name] = {"load_factor_variations": variations, "type": "nn_load_dependent",
+                                "input_dim": prop.input_dim}
+        else:
+            properties[name] = {
+                "at_nodes": {"coords": node_coords.tolist(),
+                             "values": _eval_points(prop, node_coords, None, model.dimension)},
+                "at_elements": {"centroids": cent_list,
+                                "values": _eval_points(prop, centroids, None, model.dimension)},
+                "type": "nn", "input_dim": prop.input_dim}
+    return properties
+
+
+def solve_problem(parsed_data):
+    """generic.py:447-495."""
+    model = parsed_data["model"]
+    solver_config = parsed_data["solver_config"]
+    measured_data = parsed_data.get("measured_data", {})
+    log_print(f"\n{'='*60}")
+    log_print("UNIFIED SOLVER")
+    log_print(f"{'='*60}")
+    log_print(f"Nodes: {len(model.nodes)}")
+    log_print(f"Elements: {len(model.elements)}")
+    log_print(f"Fixed DOFs: {len(model.fixed_dofs)}")
+    log_print(f"Has NN: {model.material.has_trainable_params()}")
+    log_print(f"Has measurements: {len(measured_data.get('dofs', [])) > 0}")
+    log_print(f"Solver method: {solver_config.method}")
+    result = solve(model=model, config=solver_config,
+                   measured_disp=measured_data.get("values", None),
+                   measured_dofs=measured_data.get("dofs", None))
+    output = {
+        "success": result.converged,
+        "converged": result.converged,
+        "iterations": len(result.history),
+        "displacements": result.displacements.flatten().tolist(),
+        "reactions": result.reactions.flatten().tolist() if result.reactions is not None else [],
+        "history": result.history,
+    }
+    if result.nn_parameters:
+        output["nn_parameters"] = {k: v.tolist() for k, v in result.nn_parameters.items()}
+        output["identified_properties"] = extract_nn_properties(model)
+    return output
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    if len(argv) < 2:
+        print("Usage: python generic.py problem.json [output.json]")
+        sys.exit(1)
+    problem_file = argv[1]
+    log_file = setup_logging(problem_file)
+    if len(argv) > 2:
+        output_file = argv[2]
+    else:
+        p = Path(problem_file)
+        output_file = str(p.parent / f"{p.stem}.res.json")
+    log_print(f"Output file will be: {output_file}")
+    log_print("=" * 60)
+    try:
+        log_print("\n[STEP 1] Parsing problem file...")
+        parsed = parse_problem(problem_file)
+        log_print("[OK] Problem parsed successfully")
+        log_print("\n[STEP 2] Solving problem...")
+        result = solve_problem(parsed)
+        log_print("[OK] Problem solved")
+        log_print("\n[STEP 3] Writing results...")
+        with open(output_file, "w") as f:
+            json.dump(result, f, indent=2)
+        log_print(f"[OK] Results written to {output_file}")
+        log_print(f"\n{'='*60}")
+        log_print("SOLUTION SUMMARY:")
+        if result.get("success"):
+            log_print("  Status: SUCCESS")
+            log_print(f"  Iterations: {result['iterations']}")
+            log_print(f"  Max displacement: {max(abs(d) for d in result['displacements']):.6e}")
+        else:
+            log_print("  Status: FAILED")
+        log_print(f"{'='*60}")
+        log_print("[SUCCESS] Solve completed successfully")
+        log_print(f"{'='*60}\n")
+        log_print(f"Log file saved: {log_file}")
+    except Exception as e:  # generic.py:861-867: traceback to the log, exit code 1, no error JSON
+        log_print(f"\n[ERROR] {e}", level="error")
+        import traceback
+        log_print(traceback.format_exc(), level="error")
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

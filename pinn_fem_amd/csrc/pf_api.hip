@@ -1,0 +1,356 @@
+// pf_api.hip — the C ABI declared in include/pinnfem_hip.h: argument checks, net-shape dispatch,
+// and the fused GD-iteration launch sequence (FEM/python/fem/solver.py:254-355).
+#include <string.h>
+#include <stdio.h>
+#include "pf_common.h"
+
+// launchers from pf_mesh.hip
+int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s);
+int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s);
+int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s);
+int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s);
+int pf_launch_pack_theta(const pf_problem* p, hipStream_t s);
+int pf_launch_finalize(const pf_problem* p, int mode, hipStream_t s);
+int pf_launch_reset(const pf_problem* p, hipStream_t s);
+int pf_launch_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,
+                   double beta1, double beta2, double eps, hipStream_t s);
+int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s);
+int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s);
+
+static thread_local char g_err[512] = "";
+
+void pf_set_error(const char* msg) {
+  strncpy(g_err, msg, sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+static int fail(int code, const char* msg) {
+  pf_set_error(msg);
+  return code;
+}
+
+static int check_launch(int rc, const char* what) {
+  if (rc == PF_OK) return PF_OK;
+  if (rc == PF_ERR_HIP) {
+    char buf[400];
+    snprintf(buf, sizeof(buf), "%s: HIP launch failed: %s", what, hipGetErrorString(hipGetLastError()));
+    pf_set_error(buf);
+  }
+  return rc;
+}
+
+static int padded_width(int width) {
+  if (width < 1 || width > 32) return PF_ERR_UNSUPPORTED;
+  return ((width + 3) / 4) * 4;
+}
+
+static int check_problem(const pf_problem* p) {
+  if (!p) return fail(PF_ERR_ARG, "null problem");
+  const pf_mesh& M = p->mesh;
+  if (M.dim != 1 && M.dim != 2) return fail(PF_ERR_ARG, "mesh.dim must be 1 or 2");
+  if (M.n_nodes < 1 || M.n_elems < 0 || M.n_dofs != M.n_nodes * M.dim)
+    return fail(PF_ERR_ARG, "inconsistent mesh sizes");
+  if (!M.conn || !M.egeo || !M.ecent || !M.adj_ptr || !M.adj || !M.f_ext || !M.dof_flags || !M.meas_val)
+    return fail(PF_ERR_ARG, "null mesh array");
+  if (p->n_part_blocks < 1 || p->n_part_blocks > PF_MAX_BLOCKS)
+    return fail(PF_ERR_ARG, "n_part_blocks out of range");
+  if (!p->u || !p->g_f || !p->partials || !p->state) return fail(PF_ERR_ARG, "null state/workspace");
+  for (int k = 0; k < 2; ++k) {
+    const pf_net& n = p->net[k];
+    if (!n.enabled) continue;
+    if (n.in_dim != M.dim + 1)
+      return fail(PF_ERR_ARG, "net in_dim must be mesh.dim+1 (columns load_factor, x[, y])");
+    if (padded_width(n.width) < 0 || n.n_hidden < 1 || n.n_hidden > 3)
+      return fail(PF_ERR_UNSUPPORTED, "net shape outside the compiled menu (width 1..32, hidden layers 1..3)");
+    if (!p->theta || !p->theta_pad || !p->pad_index || !p->g_ea || !p->grad_theta)
+      return fail(PF_ERR_ARG, "null parameter workspace");
+    if ((k == 0 && !p->prop_e) || (k == 1 && !p->prop_a)) return fail(PF_ERR_ARG, "null property array");
+  }
+  return PF_OK;
+}
+
+static int net_forward(const pf_problem* p, int which, hipStream_t s) {
+  switch (padded_width(p->net[which].width)) {
+    case 4: return pf_launch_net_forward_4(p, which, s);
+    case 8: return pf_launch_net_forward_8(p, which, s);
+    case 12: return pf_launch_net_forward_12(p, which, s);
+    case 16: return pf_launch_net_forward_16(p, which, s);
+    case 20: return pf_launch_net_forward_20(p, which, s);
+    case 24: return pf_launch_net_forward_24(p, which, s);
+    case 28: return pf_launch_net_forward_28(p, which, s);
+    case 32: return pf_launch_net_forward_32(p, which, s);
+  }
+  return fail(PF_ERR_UNSUPPORTED, "net width outside 1..32");
+}
+
+static int net_backward(const pf_problem* p, int which, hipStream_t s) {
+  switch (padded_width(p->net[which].width)) {
+    case 4: return pf_launch_net_backward_4(p, which, s);
+    case 8: return pf_launch_net_backward_8(p, which, s);
+    case 12: return pf_launch_net_backward_12(p, which, s);
+    case 16: return pf_launch_net_backward_16(p, which, s);
+    case 20: return pf_launch_net_backward_20(p, which, s);
+    case 24: return pf_launch_net_backward_24(p, which, s);
+    case 28: return pf_launch_net_backward_28(p, which, s);
+    case 32: return pf_launch_net_backward_32(p, which, s);
+  }
+  return fail(PF_ERR_UNSUPPORTED, "net width outside 1..32");
+}
+
+#define PF_TRY(expr, what)                       \
+  do {                                           \
+    int rc__ = check_launch((expr), what);       \
+    if (rc__ != PF_OK) return rc__;              \
+  } while (0)
+
+extern "C" {
+
+int pf_abi_version(void) { return PF_ABI_VERSION; }
+const char* pf_last_error(void) { return g_err; }
+
+int pf_sizeof(int what) {
+  switch (what) {
+    case 0: return (int)sizeof(pf_mesh);
+    case 1: return (int)sizeof(pf_net);
+    case 2: return (int)sizeof(pf_state);
+    case 3: return (int)sizeof(pf_problem);
+  }
+  return PF_ERR_ARG;
+}
+
+int pf_net_param_count(int in_dim, int width, int n_hidden) {
+  if (in_dim < 1 || width < 1 || n_hidden < 1) return PF_ERR_ARG;
+  return width * in_dim + width + (n_hidden - 1) * (width * width + width) + width + 1;
+}
+
+int pf_padded_width(int width) { return padded_width(width); }
+
+int pf_net_pad_count(int in_dim, int width, int n_hidden) {
+  const int hp = padded_width(width);
+  if (hp < 0 || n_hidden < 1 || n_hidden > 3 || (in_dim != 2 && in_dim != 3)) return PF_ERR_UNSUPPORTED;
+  return pf_pad_count(hp, n_hidden);
+}
+
+// padded-image index of torch parameter `local` (0-based inside the net's parameters() order)
+int pf_net_pad_index(int in_dim, int width, int n_hidden, int local) {
+  const int hp = padded_width(width);
+  if (hp < 0 || n_hidden < 1 || n_hidden > 3 || (in_dim != 2 && in_dim != 3)) return PF_ERR_UNSUPPORTED;
+  int q = local;
+  if (q < 0) return PF_ERR_ARG;
+  // W1 (width,in_dim), b1 (width)
+  if (q < width * in_dim) return (q / in_dim) * 4 + (q % in_dim);
+  q -= width * in_dim;
+  if (q < width) return q * 4 + in_dim;
+  q -= width;
+  for (int l = 2; l <= n_hidden; ++l) {
+    if (q < width * width) return pf_pad_wh(hp, l) + (q / width) * (hp + 4) + (q % width);
+    q -= width * width;
+    if (q < width) return pf_pad_wh(hp, l) + q * (hp + 4) + hp;
+    q -= width;
+  }
+  if (q < width) return pf_pad_wo(hp, n_hidden) + q;
+  q -= width;
+  if (q == 0) return pf_pad_wo(hp, n_hidden) + hp;
+  return PF_ERR_ARG;
+}
+
+long long pf_partials_count(const pf_problem* p) {
+  if (!p) return PF_ERR_ARG;
+  return (long long)PF_PART_WG + (long long)p->n_part_blocks * (long long)p->pad_total;
+}
+
+int pf_pack_theta(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  PF_TRY(pf_launch_pack_theta(p, (hipStream_t)stream), "pf_pack_theta");
+  return PF_OK;
+}
+
+int pf_net_forward(const pf_problem* p, int which, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (which < 0 || which > 1 || !p->net[which].enabled) return fail(PF_ERR_ARG, "net not enabled");
+  PF_TRY(net_forward(p, which, (hipStream_t)stream), "pf_net_forward");
+  return PF_OK;
+}
+
+int pf_internal_force(const pf_problem* p, const float* u, float* f_int_out, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!u || !f_int_out) return fail(PF_ERR_ARG, "null u / f_int_out");
+  pf_problem q = *p;
+  q.u = const_cast<float*>(u);
+  PF_TRY(pf_launch_node_residual(&q, f_int_out, 0, (hipStream_t)stream), "pf_internal_force");
+  return PF_OK;
+}
+
+int pf_node_residual(const pf_problem* p, float* f_int_out, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  PF_TRY(pf_launch_node_residual(p, f_int_out, 1, (hipStream_t)stream), "pf_node_residual");
+  return PF_OK;
+}
+
+int pf_elem_adjoint(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!p->g_ea) return fail(PF_ERR_ARG, "null g_ea");
+  PF_TRY(pf_launch_elem_adjoint(p, (hipStream_t)stream), "pf_elem_adjoint");
+  return PF_OK;
+}
+
+int pf_net_backward(const pf_problem* p, int which, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (which < 0 || which > 1 || !p->net[which].enabled) return fail(PF_ERR_ARG, "net not enabled");
+  PF_TRY(net_backward(p, which, (hipStream_t)stream), "pf_net_backward");
+  return PF_OK;
+}
+
+int pf_node_gradu(const pf_problem* p, int fuse_adam, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (fuse_adam && (!p->m_u || !p->v_u)) return fail(PF_ERR_ARG, "null Adam moments for u");
+  if (!fuse_adam && !p->grad_u) return fail(PF_ERR_ARG, "grad_u required when Adam is not fused");
+  PF_TRY(pf_launch_node_gradu(p, fuse_adam, (hipStream_t)stream), "pf_node_gradu");
+  return PF_OK;
+}
+
+int pf_theta_reduce(const pf_problem* p, int fuse_adam, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (fuse_adam && p->n_theta_active > 0 && (!p->m_t || !p->v_t))
+    return fail(PF_ERR_ARG, "null Adam moments for theta");
+  PF_TRY(pf_launch_theta_reduce(p, fuse_adam, (hipStream_t)stream), "pf_theta_reduce");
+  return PF_OK;
+}
+
+int pf_finalize(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  PF_TRY(pf_launch_finalize(p, 0, (hipStream_t)stream), "pf_finalize");
+  return PF_OK;
+}
+
+int pf_reset(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null Adam moments for u");
+  if (p->n_theta > 0 && (!p->m_t || !p->v_t)) return fail(PF_ERR_ARG, "null Adam moments for theta");
+  PF_TRY(pf_launch_reset(p, (hipStream_t)stream), "pf_reset");
+  return PF_OK;
+}
+
+// kernel slots of one iteration, in launch order (also the index into pf_gd_iterations_timed's output)
+enum { K_FWD_E = 0, K_FWD_A, K_RESIDUAL, K_ADJOINT, K_BWD_E, K_BWD_A, K_GRADU, K_THETA, K_FINALIZE, K_COUNT };
+
+// ev: optional array of K_COUNT+1 events; ev[k] is recorded before slot k, ev[K_COUNT] at the end
+static int enqueue_iteration(const pf_problem* p, int fuse_adam, int finalize_mode, hipStream_t s,
+                             hipEvent_t* ev) {
+  const bool any_net = p->net[0].enabled || p->net[1].enabled;
+#define PF_MARK(k) do { if (ev && hipEventRecord(ev[k], s) != hipSuccess) return fail(PF_ERR_HIP, "hipEventRecord failed"); } while (0)
+  PF_MARK(K_FWD_E);
+  if (p->net[0].enabled) PF_TRY(net_forward(p, 0, s), "net_forward");
+  PF_MARK(K_FWD_A);
+  if (p->net[1].enabled) PF_TRY(net_forward(p, 1, s), "net_forward");
+  PF_MARK(K_RESIDUAL);
+  PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
+  PF_MARK(K_ADJOINT);
+  if (any_net) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+  PF_MARK(K_BWD_E);
+  if (p->net[0].enabled) PF_TRY(net_backward(p, 0, s), "net_backward");
+  PF_MARK(K_BWD_A);
+  if (p->net[1].enabled) PF_TRY(net_backward(p, 1, s), "net_backward");
+  PF_MARK(K_GRADU);
+  PF_TRY(pf_launch_node_gradu(p, fuse_adam, s), "node_gradu");
+  PF_MARK(K_THETA);
+  if (any_net) PF_TRY(pf_launch_theta_reduce(p, fuse_adam, s), "theta_reduce");
+  PF_MARK(K_FINALIZE);
+  PF_TRY(pf_launch_finalize(p, finalize_mode, s), "finalize");
+  PF_MARK(K_COUNT);
+#undef PF_MARK
+  return PF_OK;
+}
+
+static int check_gd(const pf_problem* p) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null Adam moments for u");
+  if (p->n_theta_active > 0 && (!p->m_t || !p->v_t)) return fail(PF_ERR_ARG, "null Adam moments for theta");
+  return PF_OK;
+}
+
+int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
+  int rc = check_gd(p);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n_iter; ++i) {
+    rc = enqueue_iteration(p, 1, 0, s, nullptr);
+    if (rc) return rc;
+  }
+  return PF_OK;
+}
+
+int pf_gd_iterations_timed(const pf_problem* p, int n_iter, void* stream, float* ms_per_kernel) {
+  int rc = check_gd(p);
+  if (rc) return rc;
+  if (!ms_per_kernel || n_iter < 1) return fail(PF_ERR_ARG, "pf_gd_iterations_timed: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int per = K_COUNT + 1;
+  hipEvent_t* ev = new hipEvent_t[(size_t)n_iter * per];
+  int made = 0;
+  for (; made < n_iter * per; ++made)
+    if (hipEventCreate(&ev[made]) != hipSuccess) break;
+  rc = made == n_iter * per ? PF_OK : fail(PF_ERR_HIP, "hipEventCreate failed");
+  for (int i = 0; rc == PF_OK && i < n_iter; ++i) rc = enqueue_iteration(p, 1, 0, s, ev + (size_t)i * per);
+  if (rc == PF_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(PF_ERR_HIP, "hipStreamSynchronize failed");
+  if (rc == PF_OK) {
+    for (int k = 0; k < K_COUNT; ++k) ms_per_kernel[k] = 0.f;
+    for (int i = 0; i < n_iter; ++i)
+      for (int k = 0; k < K_COUNT; ++k) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[(size_t)i * per + k], ev[(size_t)i * per + k + 1]) != hipSuccess) {
+          rc = fail(PF_ERR_HIP, "hipEventElapsedTime failed");
+          break;
+        }
+        ms_per_kernel[k] += ms;
+      }
+    for (int k = 0; k < K_COUNT; ++k) ms_per_kernel[k] /= (float)n_iter;
+  }
+  for (int i = 0; i < made; ++i) hipEventDestroy(ev[i]);
+  delete[] ev;
+  return rc;
+}
+
+int pf_loss_and_grads(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!p->grad_u) return fail(PF_ERR_ARG, "grad_u required");
+  return enqueue_iteration(p, 0, 1, (hipStream_t)stream, nullptr);
+}
+
+int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,
+            double beta1, double beta2, double eps, void* stream) {
+  if (!param || !grad || !m || !v || n < 0 || step < 1) return fail(PF_ERR_ARG, "pf_adam: bad argument");
+  PF_TRY(pf_launch_adam(param, grad, m, v, n, step, lr, beta1, beta2, eps, (hipStream_t)stream), "pf_adam");
+  return PF_OK;
+}
+
+int pf_diag_k(const pf_problem* p, float* diag_out, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!diag_out) return fail(PF_ERR_ARG, "null diag_out");
+  PF_TRY(pf_launch_diag_k(p, diag_out, (hipStream_t)stream), "pf_diag_k");
+  return PF_OK;
+}
+
+int pf_dense_k(const pf_problem* p, float* k_out, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!k_out) return fail(PF_ERR_ARG, "null k_out");
+  if (p->mesh.n_dofs > 4096) return fail(PF_ERR_ARG, "dense K is a small-problem view (n_dofs <= 4096)");
+  PF_TRY(pf_launch_dense_k(p, k_out, (hipStream_t)stream), "pf_dense_k");
+  return PF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+"""HipEngine — host-side owner of the device buffers of one FEM model and driver of the HIP kernels.
+
+PyTorch is used for device memory and streams only; all arithmetic of the path runs in
+libpinnfem_hip.so through the C ABI (include/pinnfem_hip.h).  There is no CPU fallback: without a
+GPU or without the built library construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import PfProblem, PfState, PinnFemHipError
+from .nets import FlatTheta, NetSpec, describe_module
+from .plan import HostPlan, build_host_plan
+
+
+def _require_gpu(device=None) -> torch.device:
+    if not torch.cuda.is_available():
+        raise PinnFemHipError(
+            "no ROCm GPU visible: pinn_fem_amd runs its hot path only through the HIP kernels "
+            "(gfx950) and has no CPU fallback")
+    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+class HipEngine:
+    """Device-resident problem: mesh plan, flat theta, Adam state, workspaces."""
+
+    def __init__(self, model, measured_disp=None, measured_dofs=None, device=None,
+                 wg_mode: Optional[int] = None, n_part_blocks: Optional[int] = None,
+                 host_plan: Optional[HostPlan] = None, fe_mode: Optional[int] = None):
+        self.lib = _capi.load()
+        self.device = _require_gpu(device)
+        self.model = model
+        hp = host_plan or build_host_plan(model.nodes, model.elements, model.loads, model.fixed_dofs,
+                                          model.dimension, measured_disp, measured_dofs)
+        self.plan = hp
+        dev = self.device
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.conn, self.egeo, self.ecent = t(hp.conn), t(hp.egeo), t(hp.ecent)
+        self.adj_ptr, self.adj = t(hp.adj_ptr), t(hp.adj)
+        self.f_ext, self.dof_flags, self.meas_val = t(hp.f_ext), t(hp.dof_flags), t(hp.meas_val)
+        self.has_measurements = measured_disp is not None and measured_dofs is not None
+
+        # ---- nets: young, area evaluated; density's parameters only ride along in theta ----------
+        mat = model.material
+        self.specs: List[NetSpec] = []
+        param_lists = []
+        for prop in (mat.young, mat.area):
+            if prop.is_trainable():
+                spec = describe_module(prop.net)
+                spec.positive = bool(prop.enforce_positive)
+                spec.scale = float(prop.scale)
+                if spec.in_dim != model.dimension + 1:
+                    # the reference feeds [load_factor, x(, y)] whatever input_dim says
+                    # (properties.py:116-125) and torch then raises a shape error
+                    raise RuntimeError(
+                        f"mat1 and mat2 shapes cannot be multiplied: NN input has {model.dimension + 1} "
+                        f"columns [load_factor, x(, y)] but the net expects {spec.in_dim}")
+                param_lists.append(prop.get_torch_params())
+            else:
+                spec = NetSpec(enabled=False, scale=float(prop.value()))
+            self.specs.append(spec)
+        n_active = sum(p.numel() for lst in param_lists for p in lst)
+        if mat.density.is_trainable():
+            param_lists.append(mat.density.get_torch_params())
+        self.theta = FlatTheta(param_lists, dev)
+        self.n_theta = self.theta.n
+        self.n_theta_active = n_active
+        self.tensor_off = torch.tensor(self.theta.tensor_off, dtype=torch.int32, device=dev)
+
+        lib = self.lib
+        pad_off, theta_off, pad_index = 0, 0, []
+        self._net_offsets = []
+        for spec in self.specs:
+            if not spec.enabled:
+                self._net_offsets.append((0, 0))
+                continue
+            cnt = lib.pf_net_pad_count(spec.in_dim, spec.width, spec.n_hidden)
+            _capi.check(min(cnt, 0), "pf_net_pad_count")
+            self._net_offsets.append((theta_off, pad_off))
+            for q in range(spec.n_params):
+                pad_index.append(pad_off + lib.pf_net_pad_index(spec.in_dim, spec.width, spec.n_hidden, q))
+            pad_off += cnt
+            theta_off += spec.n_params
+        self.pad_total = pad_off
+        self.pad_index = torch.tensor(pad_index if pad_index else [0], dtype=torch.int32, device=dev)
+
+        if wg_mode is None:
+            wg_mode = int(os.environ.get("PINNFEM_WG_MODE", _capi.PF_WG_MFMA))
+        self.wg_mode = wg_mode
+        if fe_mode is None:
+            fe_mode = int(os.environ.get("PINNFEM_FE_MODE", _capi.PF_FE_REFERENCE))
+        self.fe_mode = fe_mode
+        if n_part_blocks is None:
+            n_part_blocks = int(os.environ.get("PINNFEM_PART_BLOCKS", 1024))
+        self.n_part_blocks = max(1, min(int(n_part_blocks), _capi.PF_MAX_BLOCKS))
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        nd, ne = hp.n_dofs, max(hp.n_elems, 1)
+        self.u = torch.zeros(nd, **f32)
+        self.m_u = torch.zeros(nd, **f32)
+        self.v_u = torch.zeros(nd, **f32)
+        self.m_t = torch.zeros(max(self.n_theta, 1), **f32)
+        self.v_t = torch.zeros(max(self.n_theta, 1), **f32)
+        self.theta_pad = torch.zeros(max(self.pad_total, 1), **f32)
+        self.prop_e = torch.zeros(ne, **f32)
+        self.prop_a = torch.zeros(ne, **f32)
+        self.g_f = torch.zeros(nd, **f32)
+        self.g_ea = torch.zeros(ne, **f32)
+        self.grad_u = torch.zeros(nd, **f32)
+        self.grad_theta = torch.zeros(max(self.n_theta, 1), **f32)
+        self.partials = torch.zeros(3 * _capi.PF_MAX_BLOCKS + self.n_part_blocks * max(self.pad_total, 1), **f32)
+        self.state_t = torch.zeros(C.sizeof(PfState) // 4, dtype=torch.int32, device=dev)
+        self.hist = torch.zeros(1, **f32)
+        self.hist_rows = 0
+        self.P = PfProblem()
+        self._configured = False
+        self.configure(lam=1.0)
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def configure(self, lam: float, alpha_physics: float = 1.0, alpha_data: float = 100.0,
+                  lr_u: float = 1e-7, lr_t: float = 1e-4, tol: float = 1e-6, max_iter: int = 0,
+                  want_history: bool = True, want_grad_u: bool = False):
+        """Fill the pf_problem record (scalars of SolverConfig + pointers)."""
+        hp, P = self.plan, self.P
+        M = P.mesh
+        M.dim, M.n_nodes, M.n_elems, M.n_dofs = hp.dim, hp.n_nodes, hp.n_elems, hp.n_dofs
+        M.conn, M.egeo, M.ecent = self.conn.data_ptr(), self.egeo.data_ptr(), self.ecent.data_ptr()
+        M.adj_ptr, M.adj = self.adj_ptr.data_ptr(), self.adj.data_ptr()
+        M.f_ext, M.dof_flags, M.meas_val = (self.f_ext.data_ptr(), self.dof_flags.data_ptr(),
+                                            self.meas_val.data_ptr())
+        M.n_meas = hp.n_meas
+        for k, spec in enumerate(self.specs):
+            n = P.net[k]
+            n.enabled = int(spec.enabled)
+            n.in_dim, n.width, n.n_hidden = spec.in_dim, spec.width, spec.n_hidden
+            n.positive, n.scale = int(spec.positive), float(spec.scale)
+            n.theta_off, n.pad_off = self._net_offsets[k]
+        P.u, P.m_u, P.v_u = self.u.data_ptr(), self.m_u.data_ptr(), self.v_u.data_ptr()
+        P.theta, P.m_t, P.v_t = self.theta.flat.data_ptr(), self.m_t.data_ptr(), self.v_t.data_ptr()
+        P.n_theta, P.n_theta_active = self.n_theta, self.n_theta_active
+        P.tensor_off, P.n_tensors = self.tensor_off.data_ptr(), len(self.theta.tensor_off) - 1
+        P.wg_mode = self.wg_mode
+        P.lam, P.alpha_physics, P.alpha_data = float(lam), float(alpha_physics), float(alpha_data)
+        P.lr_u, P.lr_t, P.tol = float(lr_u), float(lr_t), float(tol)
+        P.beta1, P.beta2, P.eps = 0.9, 0.999, 1e-8          # torch.optim.Adam defaults (solver.py:234)
+        P.use_data = int(self.has_measurements and alpha_data > 0)   # solver.py:273
+        P.max_iter = int(max_iter)
+        P.theta_pad, P.prop_e, P.prop_a = (self.theta_pad.data_ptr(), self.prop_e.data_ptr(),
+                                           self.prop_a.data_ptr())
+        P.g_f, P.g_ea = self.g_f.data_ptr(), self.g_ea.data_ptr()
+        P.grad_u = self.grad_u.data_ptr() if want_grad_u else None
+        P.grad_theta, P.partials = self.grad_theta.data_ptr(), self.partials.data_ptr()
+        if want_history and max_iter > 0:
+            if self.hist_rows < max_iter:
+                self.hist = torch.zeros(max_iter * _capi.PF_HIST_COLS, dtype=torch.float32,
+                                        device=self.device)
+                self.hist_rows = max_iter
+            P.hist = self.hist.data_ptr()
+        else:
+            P.hist = None
+        P.state = self.state_t.data_ptr()
+        P.n_part_blocks, P.pad_total = self.n_part_blocks, self.pad_total
+        P.pad_index = self.pad_index.data_ptr()
+        P.n_meas_f = float(hp.n_meas)
+        P.fe_mode = int(self.fe_mode)
+        self._configured = True
+
+    def _ref(self):
+        return C.byref(self.P)
+
+    # ---- solve_gd support ------------------------------------------------------------------------
+    def begin(self, u_initial, lam, config, max_iter: Optional[int] = None, want_history=True):
+        """Start one solve_gd call: fresh Adam state (solver.py:234-238), u = warm start or 0."""
+        if self.n_theta and not self.theta.still_bound():
+            raise PinnFemHipError("a network parameter was re-assigned outside the engine; "
+                                  "rebuild the engine for this model")
+        self.configure(lam=lam, alpha_physics=config.alpha_physics, alpha_data=config.alpha_data,
+                       lr_u=config.learning_rate_u, lr_t=config.learning_rate_theta,
+                       tol=config.tolerance,
+                       max_iter=config.max_iterations if max_iter is None else max_iter,
+                       want_history=want_history)
+        if u_initial is None:
+            self.u.zero_()
+        else:
+            src = u_initial.detach() if isinstance(u_initial, torch.Tensor) else torch.as_tensor(
+                np.asarray(u_initial))
+            self.u.copy_(src.reshape(-1).to(device=self.device, dtype=torch.float32))
+        s = self._stream()
+        _capi.check(self.lib.pf_reset(self._ref(), s), "pf_reset")
+        _capi.check(self.lib.pf_pack_theta(self._ref(), s), "pf_pack_theta")
+
+    def iterate(self, n_iter: int):
+        _capi.check(self.lib.pf_gd_iterations(self._ref(), int(n_iter), self._stream()),
+                    "pf_gd_iterations")
+
+    def iterate_timed(self, n_iter: int) -> np.ndarray:
+        """Like iterate() but with HIP events around every kernel; synchronises.  Returns the average
+        milliseconds of each kernel slot (_capi.KERNEL_SLOT_NAMES)."""
+        out = (C.c_float * _capi.PF_KERNEL_SLOTS)()
+        _capi.check(self.lib.pf_gd_iterations_timed(self._ref(), int(n_iter), self._stream(), out),
+                    "pf_gd_iterations_timed")
+        return np.array(list(out), dtype=np.float64)
+
+    def state(self) -> PfState:
+        raw = self.state_t.cpu().numpy().tobytes()
+        return PfState.from_buffer_copy(raw)
+
+    def history(self, n_rows: int) -> np.ndarray:
+        if n_rows <= 0 or self.P.hist is None:
+            return np.zeros((0, _capi.PF_HIST_COLS), dtype=np.float32)
+        return self.hist[: n_rows * _capi.PF_HIST_COLS].cpu().numpy().reshape(n_rows, _capi.PF_HIST_COLS)
+
+    # ---- building blocks -------------------------------------------------------------------------
+    def eval_properties(self, lam: Optional[float] = None):
+        """young/area per element with the current theta (pf_pack_theta + pf_net_forward)."""
+        if lam is not None:
+            self.P.lam = float(lam)
+        s = self._stream()
+        self._clear_done()
+        _capi.check(self.lib.pf_pack_theta(self._ref(), s), "pf_pack_theta")
+        for k, spec in enumerate(self.specs):
+            if spec.enabled:
+                _capi.check(self.lib.pf_net_forward(self._ref(), k, s), "pf_net_forward")
+
+    def _clear_done(self):
+        # building-block calls outside a solve_gd run must not be masked by a finished run
+        self.state_t[1] = 0
+
+    def internal_force(self, u: Optional[torch.Tensor] = None, lam: Optional[float] = None) -> torch.Tensor:
+        """f_int = K(theta) u, re-evaluating the nets (the reference's no-grad re-assembly,
+        solver.py:374-377)."""
+        self.eval_properties(lam)
+        uu = self.u if u is None else u.to(device=self.device, dtype=torch.float32).contiguous()
+        out = torch.empty(self.plan.n_dofs, dtype=torch.float32, device=self.device)
+        _capi.check(self.lib.pf_internal_force(self._ref(), uu.data_ptr(), out.data_ptr(), self._stream()),
+                    "pf_internal_force")
+        return out
+
+    def loss_and_grads(self, u: torch.Tensor, lam: float, alpha_physics=1.0, alpha_data=100.0):
+        """One forward+backward without optimiser step.  Returns (dict of loss terms, grad_u,
+        grad_theta) as device tensors (views of engine workspaces)."""
+        self.configure(lam=lam, alpha_physics=alpha_physics, alpha_data=alpha_data, want_history=False,
+                       want_grad_u=True)
+        self.u.copy_(u.reshape(-1).to(device=self.device, dtype=torch.float32))
+        s = self._stream()
+        self._clear_done()
+        _capi.check(self.lib.pf_pack_theta(self._ref(), s), "pf_pack_theta")
+        _capi.check(self.lib.pf_loss_and_grads(self._ref(), s), "pf_loss_and_grads")
+        st = self.state()
+        losses = dict(loss_total=st.loss_total, loss_physics=st.loss_physics, loss_data=st.loss_data,
+                      residual_norm=st.residual_norm)
+        return losses, self.grad_u, self.grad_theta[: max(self.n_theta_active, 0)]
+
+    def vjp(self, u: torch.Tensor, g_f: torch.Tensor, lam: float):
+        """(K^T g_f, d(g_f . f_int)/dtheta): the backward of f_int = K(theta) u for an arbitrary
+        upstream gradient (autograd.Function backward)."""
+        self.configure(lam=lam, alpha_data=0.0, want_history=False, want_grad_u=True)
+        self.P.use_data = 0
+        self.u.copy_(u.reshape(-1).to(device=self.device, dtype=torch.float32))
+        self.g_f.copy_(g_f.reshape(-1).to(device=self.device, dtype=torch.float32))
+        s, lib, ref = self._stream(), self.lib, self._ref()
+        self._clear_done()
+        _capi.check(lib.pf_pack_theta(ref, s), "pf_pack_theta")
+        any_net = False
+        for k, spec in enumerate(self.specs):
+            if spec.enabled:
+                any_net = True
+                _capi.check(lib.pf_net_forward(ref, k, s), "pf_net_forward")
+        if any_net:
+            _capi.check(lib.pf_elem_adjoint(ref, s), "pf_elem_adjoint")
+            for k, spec in enumerate(self.specs):
+                if spec.enabled:
+                    _capi.check(lib.pf_net_backward(ref, k, s), "pf_net_backward")
+        _capi.check(lib.pf_node_gradu(ref, 0, s), "pf_node_gradu")
+        if any_net:
+            _capi.check(lib.pf_theta_reduce(ref, 0, s), "pf_theta_reduce")
+        return self.grad_u, self.grad_theta[: max(self.n_theta_active, 0)]
+
+    def diag_k(self, lam: Optional[float] = None) -> torch.Tensor:
+        self.eval_properties(lam)
+        out = torch.empty(self.plan.n_dofs, dtype=torch.float32, device=self.device)
+        _capi.check(self.lib.pf_diag_k(self._ref(), out.data_ptr(), self._stream()), "pf_diag_k")
+        return out
+
+    def dense_k(self, lam: Optional[float] = None) -> torch.Tensor:
+        self.eval_properties(lam)
+        n = self.plan.n_dofs
+        out = torch.zeros((n, n), dtype=torch.float32, device=self.device)
+        _capi.check(self.lib.pf_dense_k(self._ref(), out.data_ptr(), self._stream()), "pf_dense_k")
+        return out

@@ -1,0 +1,349 @@
+"""Unified solver — drop-in for the GD path of the reference's FEM/python/fem/solver.py.
+
+Same names, signatures, dataclass fields, history keys and control flow:
+  SolverConfig (:35-62), SolverResult (:65-75), solve_gd (:83-400), solve_hybrid (:520-692),
+  solve (:1045-1167).
+What changed is the body of the GD iteration (:254-355): instead of a Python loop over elements with
+batch-1 MLP calls, 20 indexed `+=` per element into a dense K, autograd and two torch.optim.Adam
+steps, each iteration is a fixed sequence of HIP kernels (pf_gd_iterations) working on device-
+resident state; the stop test runs on the device, so the host only polls a 64-byte state record
+every `check_every` iterations and the final state equals the reference's `break`.
+
+Out of scope here: solve_nr (:408-512) and solve_full_nr (:753-1037); calling them
+raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import copy
+import os
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .model import FEMModel
+from ..engine import HipEngine
+
+
+@dataclass
+class SolverConfig:
+    """Unified configuration for all solvers (solver.py:35-62)."""
+    max_iterations: int = 1000
+    tolerance: float = 1e-6
+    print_every: int = 10
+    n_increments: int = 10
+    load_factor_initial: float = 0.0
+    load_factor_final: float = 1.0
+    min_denominator: float = 1e-10
+    learning_rate_u: float = 1e-7
+    learning_rate_theta: float = 1e-4
+    alpha_physics: float = 1.0
+    alpha_data: float = 100.0
+    method: str = "auto"
+    preconditioning: bool = False
+
+
+@dataclass
+class SolverResult:
+    """Unified result from any solver (solver.py:65-75)."""
+    displacements: np.ndarray
+    reactions: np.ndarray
+    converged: bool
+    history: List[Dict[str, float]] = field(default_factory=list)
+    nn_parameters: Optional[Dict[str, np.ndarray]] = None
+
+
+# host polls the device state every CHECK_EVERY iterations (launches after the stop are no-ops)
+CHECK_EVERY = int(os.environ.get("PINNFEM_CHECK_EVERY", 50))
+VERBOSE = os.environ.get("PINNFEM_QUIET", "0") != "1"
+
+
+def _say(msg: str = ""):
+    if VERBOSE:
+        print(msg)
+
+
+def _engine_for(model: FEMModel, measured_disp, measured_dofs) -> HipEngine:
+    """One engine (mesh plan + device buffers) per model and measurement set, reused across load
+    increments and phases like the reference reuses the nn.Modules."""
+    key = (None if measured_disp is None else np.asarray(measured_disp, dtype=float).tobytes(),
+           None if measured_dofs is None else np.asarray(measured_dofs, dtype=int).tobytes(),
+           model.nodes.tobytes(), model.elements.tobytes(), model.loads.tobytes(),
+           model.fixed_dofs.tobytes())
+    cache = getattr(model, "_pf_engine_cache", None)
+    if cache is not None and cache[0] == key and (not cache[1].n_theta or cache[1].theta.still_bound()):
+        return cache[1]
+    eng = HipEngine(model, measured_disp, measured_dofs)
+    model._pf_engine_cache = (key, eng)
+    return eng
+
+
+def solve_gd(
+    model: FEMModel,
+    config: Optional[SolverConfig] = None,
+    measured_disp: Optional[np.ndarray] = None,
+    measured_dofs: Optional[List[int]] = None,
+    target_load_factor: float = 1.0,
+    u_initial: Optional[torch.Tensor] = None,
+    skip_preconditioning: bool = False,
+) -> SolverResult:
+    """Gradient Descent solver for FEM/PINN problems (solver.py:83-400)."""
+    config = config or SolverConfig()
+
+    # ---- two-phase "preconditioning" schedule (solver.py:113-198) --------------------------------
+    if config.preconditioning and not skip_preconditioning:
+        _say("GD Preconditioning phase...")
+        precon_config = copy.deepcopy(config)
+        precon_config.max_iterations = min(300, config.max_iterations // 3)
+        precon_config.tolerance = max(1e-4, config.tolerance * 10)
+        precon_config.preconditioning = False
+        try:
+            precon_result = solve_gd(model, precon_config, measured_disp, measured_dofs,
+                                     target_load_factor, u_initial, skip_preconditioning=True)
+            _say(f"  Preconditioning: {precon_result.history[-1]['iteration']} iterations")
+            if (precon_result.converged
+                    and precon_result.history[-1].get("residual_norm", 1.0) < config.tolerance):
+                _say("  Preconditioning achieved final convergence")
+                return precon_result
+            u_initial = torch.tensor(precon_result.displacements.flatten(), dtype=torch.float32)
+            _say("Main GD phase (tight tolerance)...")
+            main_config = copy.deepcopy(config)
+            main_config.max_iterations = config.max_iterations - precon_config.max_iterations
+            main_config.preconditioning = False
+            main_result = solve_gd(model, main_config, measured_disp, measured_dofs,
+                                   target_load_factor, u_initial, skip_preconditioning=True)
+            precon_iterations = (precon_result.history[-1].get("iteration", 0)
+                                 if precon_result.history else 0)
+            unified_history = []
+            if precon_result.history:
+                unified_history.extend(precon_result.history)
+            if main_result.history:
+                for entry in main_result.history:
+                    new_entry = entry.copy()
+                    new_entry["iteration"] = entry.get("iteration", 0) + precon_iterations
+                    unified_history.append(new_entry)
+            main_result.history = unified_history
+            total_iterations = (main_result.history[-1].get("iteration", 0)
+                                if main_result.history else 0)
+            _say(f"  Total GD (with preconditioning): {total_iterations} iterations")
+            return main_result
+        except NotImplementedError:
+            raise
+        except Exception as e:  # solver.py:197-198 swallows and falls through to plain GD
+            _say(f"  Preconditioning failed: {e}, proceeding with standard GD")
+
+    has_nn = model.material.has_trainable_params()
+    theta_list = model.material.get_all_torch_params() if has_nn else []
+    eng = _engine_for(model, measured_disp, measured_dofs)
+    has_measurements = measured_disp is not None and measured_dofs is not None
+    if u_initial is not None:
+        _say("  🔥 Using warm start from previous increment")
+    else:
+        _say("  ❄️  Cold start from zeros")
+    if has_measurements and config.alpha_data == 0.0:
+        _say("⚠️  Warning: measured_dofs provided but alpha_data=0.0")
+
+    header = (f"{'Iter':>6} | {'Loss Total':>12} | {'Loss Physics':>12} | {'||R||':>12} | "
+              f"{'Loss Data':>12} | {'||u||':>10}")
+    if has_nn:
+        header += f" | {'NN Params':>10}"
+    _say(header)
+    _say("-" * (82 + (12 if has_nn else 0)))
+
+    # ---- the hot loop (solver.py:252-355) on the device --------------------------------------------
+    eng.begin(u_initial, target_load_factor, config)
+    n_done = 0
+    st = None
+    while n_done < config.max_iterations:
+        chunk = min(CHECK_EVERY, config.max_iterations - n_done)
+        eng.iterate(chunk)
+        st = eng.state()                       # one small D2H copy + sync per chunk
+        n_done = st.iter
+        if st.done:
+            break
+    n_iter = st.iter if st is not None else 0
+    converged = bool(st.converged) if st is not None else False
+    rows = eng.history(n_iter)
+
+    history: List[Dict[str, float]] = []
+    for it in range(n_iter):
+        r = rows[it]
+        entry = {
+            "iteration": float(it + 1),
+            "loss_total": float(r[0]),
+            "loss_physics": float(r[1]),
+            "loss_data": float(r[2]) if has_measurements else 0.0,
+            "u_norm": float(r[3]),
+            "residual_norm": float(r[4]),
+        }
+        if theta_list:
+            entry["theta_norm"] = float(r[5])
+        history.append(entry)
+        if VERBOSE and ((it + 1) % config.print_every == 0 or it == 0):
+            msg = (f"{it+1:6d} | {entry['loss_total']:12.3e} | {entry['loss_physics']:12.3e} | "
+                   f"{entry['residual_norm']:12.3e} | {entry['loss_data']:12.3e} | {entry['u_norm']:10.3e}")
+            if has_nn:
+                msg += f" | {entry['theta_norm']:10.3e}"
+            print(msg)
+    if converged:
+        last = history[-1]
+        if last["residual_norm"] < config.tolerance:
+            _say(f"\n[CONVERGED] Reached equilibrium in {n_iter} iterations "
+                 f"(residual={last['residual_norm']:.2e} < tol={config.tolerance:.1e})")
+        else:
+            _say(f"\n[CONVERGED] Loss minimized in {n_iter} iterations "
+                 f"(loss={last['loss_total']:.2e} < tol={config.tolerance:.1e})")
+    else:
+        _say(f"\n[WARNING] Did not converge in {config.max_iterations} iterations.")
+        if history:
+            _say(f"          Final loss: {history[-1]['loss_total']:.3e}")
+
+    # ---- result (solver.py:365-400) -----------------------------------------------------------------
+    u_final = eng.u.detach().cpu().numpy().copy()
+    shape = (-1, 1) if model.dimension == 1 else (model.nnode, model.dimension)
+    displacements_out = u_final.reshape(shape)
+    f_int_final = eng.internal_force(lam=target_load_factor)           # no-grad re-assembly :374-377
+    reactions_t = f_int_final - float(np.float32(target_load_factor)) * eng.f_ext
+    reactions_np = reactions_t.cpu().numpy()
+    reactions_np[eng.plan.free_dofs] = 0.0                            # :379
+    reactions_out = reactions_np.reshape(shape)
+    nn_params = None
+    if theta_list:
+        nn_params = {f"param_{i}": p.detach().cpu().numpy() for i, p in enumerate(theta_list)}
+    return SolverResult(displacements=displacements_out, reactions=reactions_out,
+                        converged=converged, history=history, nn_parameters=nn_params)
+
+
+def solve_nr(model, config=None, target_load_factor=1.0, u_initial=None) -> SolverResult:
+    """Classical Newton-Raphson (solver.py:408-512) — out of scope of the HIP path."""
+    raise NotImplementedError(
+        "solve_nr (dense NumPy Newton-Raphson, scalar materials only) is outside the accelerated "
+        "PINN+GD path; use the reference implementation for method='nr'")
+
+
+def solve_full_nr(*args, **kwargs) -> SolverResult:
+    """solver.py:753-1037 — out of scope (and non-functional in the reference)."""
+    raise NotImplementedError("solve_full_nr is outside the accelerated PINN+GD path")
+
+
+def solve_hybrid(
+    model: FEMModel,
+    config: Optional[SolverConfig] = None,
+    measured_disp: Optional[np.ndarray] = None,
+    measured_dofs: Optional[List[int]] = None,
+    target_load_factor: float = 1.0,
+    u_initial: Optional[torch.Tensor] = None,
+) -> SolverResult:
+    """Hybrid solver (solver.py:520-692).  With NN materials phase 2 is GD again (:594-651)."""
+    config = config or SolverConfig()
+    _say("=== HYBRID SOLVER ===")
+    _say(f"Target load factor: {target_load_factor}")
+    gd_result = None
+    gd_config = None
+    if config.preconditioning:
+        _say("Phase 1: GD Preconditioning...")
+        gd_config = copy.deepcopy(config)
+        gd_config.max_iterations = min(300, config.max_iterations // 3)
+        gd_config.tolerance = max(1e-4, config.tolerance * 10)
+        try:
+            gd_result = solve_gd(model, gd_config, measured_disp, measured_dofs, target_load_factor,
+                                 u_initial, skip_preconditioning=True)
+            _say(f"  GD Phase: {gd_result.history[-1]['iteration']} iterations")
+            if (gd_result.converged
+                    and gd_result.history[-1].get("residual_norm", 1.0) < config.tolerance):
+                _say("  GD achieved tight convergence, skipping NR phase")
+                return gd_result
+        except NotImplementedError:
+            raise
+        except Exception as e:  # solver.py:584-586
+            _say(f"  GD Phase failed: {e}, proceeding with cold NR")
+            gd_result = None
+    else:
+        _say("Phase 1: GD Preconditioning SKIPPED (preconditioning=False)")
+
+    _say("Phase 2: Newton-Raphson Finalization...")
+    has_nn = model.material.has_trainable_params()
+    if not has_nn:
+        # scalar materials switch to the dense NumPy Newton-Raphson (solver.py:653-692): out of scope
+        return solve_nr(model, config, target_load_factor, u_initial)
+    _say("  NN parameters detected. Using GD for final convergence with tight tolerance.")
+    final_config = copy.deepcopy(config)
+    final_config.max_iterations = config.max_iterations - (gd_config.max_iterations if gd_result else 0)
+    final_config.tolerance = config.tolerance
+    u_warm = (torch.tensor(gd_result.displacements.flatten(), dtype=torch.float32)
+              if gd_result else u_initial)
+    final_result = solve_gd(model, final_config, measured_disp, measured_dofs, target_load_factor,
+                            u_warm, skip_preconditioning=True)
+    if gd_result:
+        gd_iterations = gd_result.history[-1].get("iteration", 0) if gd_result.history else 0
+        unified_history = []
+        if gd_result.history:
+            unified_history.extend(gd_result.history)
+        if final_result.history:
+            for entry in final_result.history:
+                new_entry = entry.copy()
+                new_entry["iteration"] = entry.get("iteration", 0) + gd_iterations
+                unified_history.append(new_entry)
+        final_result.history = unified_history
+    total_iterations = final_result.history[-1].get("iteration", 0) if final_result.history else 0
+    _say(f"  Hybrid Total: {total_iterations} iterations")
+    return final_result
+
+
+def solve(
+    model: FEMModel,
+    config: Optional[SolverConfig] = None,
+    measured_disp: Optional[np.ndarray] = None,
+    measured_dofs: Optional[List[int]] = None,
+) -> SolverResult:
+    """Universal solver with incremental loading (solver.py:1045-1167)."""
+    config = config or SolverConfig()
+    if config.method != "auto":
+        method = config.method.lower()
+    else:
+        has_nn = model.material.has_trainable_params()
+        has_measurements = measured_disp is not None and measured_dofs is not None
+        if not has_nn and not has_measurements:
+            _say("[AUTO] Selecting: Newton-Raphson (classical FEM)")
+            method = "nr"
+        elif has_nn:
+            _say("[AUTO] Selecting: Gradient Descent (PINN)")
+            method = "gd"
+        else:
+            _say("[AUTO] Selecting: Gradient Descent (inverse problem)")
+            method = "gd"
+
+    _say(f"\n{'Inc':>4} | {'Load Factor':>12} | {'Status':>10}")
+    _say("-" * 40)
+    result = None
+    u_current = None
+    for iinc in range(1, config.n_increments + 1):
+        load_factor = config.load_factor_initial + (iinc / config.n_increments) * (
+            config.load_factor_final - config.load_factor_initial)
+        _say(f"{iinc:>4} | {load_factor:>12.4f} | {'WARM_START' if u_current is not None else 'COLD_START':>10}")
+        u_initial_torch = None
+        if u_current is not None:
+            u_initial_torch = torch.tensor(u_current, dtype=torch.float32, requires_grad=False)
+            _say(f"    Warm start values: shape={u_initial_torch.shape}, "
+                 f"range=[{u_initial_torch.min():.4f}, {u_initial_torch.max():.4f}]")
+        if method == "gd":
+            result = solve_gd(model, config, measured_disp, measured_dofs,
+                              target_load_factor=load_factor, u_initial=u_initial_torch)
+        elif method == "nr":
+            result = solve_nr(model, config, target_load_factor=load_factor, u_initial=u_initial_torch)
+        elif method == "hybrid":
+            result = solve_hybrid(model, config, measured_disp, measured_dofs,
+                                  target_load_factor=load_factor, u_initial=u_initial_torch)
+        elif method == "full-nr":
+            result = solve_full_nr(model, config, measured_disp, measured_dofs,
+                                   target_load_factor=load_factor)
+        else:
+            raise ValueError(f"Unknown solver method: {method}")
+        u_current = result.displacements.flatten()
+        status = "CONVERGED" if result.converged else "FAILED"
+        _say(f"{iinc:4d} | {load_factor:12.6f} | {status:>10}")
+        if not result.converged:
+            _say(f"[WARNING] Increment {iinc} did not converge, stopping incremental loading.")
+            break
+    return result

@@ -138,3 +138,46 @@ def rel_err(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = max(np.max(np.abs(b)), 1e-30)
     return float(np.max(np.abs(a - b)) / den)
+
+
+# ---------------------------------------------------------------------------------------------
+# product-side model construction from fixtures (used by the GPU parity tests)
+# ---------------------------------------------------------------------------------------------
+def product_model(nodes, elements, loads, fixed, dim, widths, scales, theta, in_dim=None):
+    """pinn_fem_amd FEMModel whose nets carry the fixture's parameters (CPU modules; the engine
+    moves them to the device).  widths: per property hidden width or None (scalar)."""
+    import torch
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.properties import NNProperty
+    from pinn_fem_amd.nets import SimpleNN
+
+    in_dim = in_dim or dim + 1
+    nets = split_nets(theta) if theta else []
+    props, k = [], 0
+    for w, sc in zip(widths, scales):
+        if w is None:
+            props.append(float(sc))
+            continue
+        net = SimpleNN(hidden_layers=2, neurons_per_layer=w, input_dim=in_dim)
+        with torch.no_grad():
+            for p, a in zip(net.parameters(), nets[k]):
+                p.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(p.shape))
+        props.append(NNProperty(net=net, input_dim=in_dim, enforce_positive=True, scale=float(sc)))
+        k += 1
+    mat = Material(young=props[0], area=props[1], density=props[2])
+    return FEMModel(nodes=nodes, elements=elements, material=mat, loads=loads, fixed_dofs=fixed,
+                    dimension=dim)
+
+
+def product_example(example, theta=None):
+    """(parsed dict from pinn_fem_amd.cli.generic.parse_problem, with fixture theta loaded)."""
+    import torch
+    from pinn_fem_amd.cli import generic as g
+    parsed = g.parse_problem(input_json(example))
+    if theta is not None:
+        params = parsed["model"].material.get_all_torch_params()
+        assert len(params) == len(theta)
+        with torch.no_grad():
+            for p, a in zip(params, theta):
+                p.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)).reshape(p.shape))
+    return parsed
