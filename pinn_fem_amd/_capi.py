@@ -120,6 +120,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7: import it first so that this library binds to the
+    # SAME HIP runtime instance (two runtimes in one process see no device)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise PinnFemHipError(
             f"{LIB_PATH} not found: the HIP library is not built. Run `python -m pinn_fem_amd.build` "

@@ -217,7 +217,11 @@ def test_oracle_parity_chain_sizes(n, fe):
     assert abs(losses["loss_data"] - ref.loss_data) < 1e-5 * max(ref.loss_data, 1e-12)
     if fe == 1 or n <= 129:
         assert abs(losses["loss_physics"] - ref.loss_physics) < 1e-4 * max(ref.loss_physics, 1e-12)
-        assert np.max(np.abs(gu - ref.grad_u)) < 5e-5 * max(np.max(np.abs(ref.grad_u)), 1e-30)
+        # fe=0: the float32 noise of f_int (|ke||u| * 2^-24) is amplified once more by |ke| in K^T g_f
+        g_tol = 5e-5 * max(np.max(np.abs(ref.grad_u)), 1e-30)
+        if fe == 0:
+            g_tol = max(g_tol, 4e-6 * scale * np.max(np.abs(ref.stiffness)))
+        assert np.max(np.abs(gu - ref.grad_u)) < g_tol
         ref_t = np.concatenate([g.reshape(-1) for g in ref.grad_theta if g is not None])
         assert rel_err(gt, ref_t) < 5e-4
 
