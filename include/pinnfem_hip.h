@@ -37,6 +37,8 @@ extern "C" {
 /* dof flag bits (pf_mesh.dof_flags) */
 #define PF_DOF_FIXED 1u
 #define PF_DOF_MEASURED 2u
+#define PF_DOF_SHARED 4u   /* dof of a node that also belongs to another rank's shard (multi-GPU) */
+#define PF_DOF_GHOST 8u    /* shared and owned by another rank: excluded from this rank's global sums */
 
 /* weight-gradient reduction engines for pf_net_backward */
 #define PF_WG_SHUFFLE 0 /* wave shuffles, VALU only (slow, simple) */
@@ -133,8 +135,13 @@ typedef struct pf_problem {
   int32_t n_part_blocks;   /* grid size used for partial sums (host picks, <= PF_MAX_BLOCKS) */
   int32_t pad_total;       /* floats of the padded-parameter image of all active nets */
   const int32_t* pad_index;/* dev [n_theta_active] torch-layout index -> padded-image index */
-  float n_meas_f;          /* (float)mesh.n_meas */
+  float n_meas_f;          /* (float)mesh.n_meas; multi-GPU: the GLOBAL count */
   int32_t fe_mode;         /* PF_FE_* : how fe = ke @ u_e is evaluated */
+  /* multi-GPU shard interface (NULL / 0 on one GPU): dofs of nodes shared with other ranks */
+  const int32_t* shared_dofs; /* dev [n_shared] local dof index */
+  const int32_t* shared_slot; /* dev [n_shared] position in the global interface vector */
+  int32_t n_shared;
+  int32_t n_iface;         /* length of the global interface vector */
 } pf_problem;
 
 #define PF_MAX_BLOCKS 1024
@@ -198,6 +205,27 @@ int pf_gd_iterations_timed(const pf_problem* p, int n_iter, void* stream, float*
 /* loss and gradients only (no optimiser): what torch.autograd.Function.forward/backward need.
  * Requires p->grad_u != NULL.  Leaves loss terms in p->state, gradients in grad_u/grad_theta. */
 int pf_loss_and_grads(const pf_problem* p, void* stream);
+
+/* ---- multi-GPU shard interface (elements sharded across ranks) ------------------
+ * No reference analogue: the reference is single-process.  A shard assembles only its own elements;
+ * nodes shared with another shard get their f_int / grad_u completed by an all-reduce (RCCL) of a
+ * short interface vector that the host issues between these calls. */
+/* iface[slot] = vec[shared_dof] for this rank's shared dofs, other slots 0.  iface dev [n_iface] */
+int pf_iface_pack(const pf_problem* p, const float* vec, float* iface, void* stream);
+/* after the all-reduce of f_int on the interface: residual, dL/df_int and loss sums of the shared
+ * dofs (owner rank only for the sums); writes p->g_f and the extra partial slot. */
+int pf_iface_fix_residual(const pf_problem* p, const float* iface, void* stream);
+/* local sums of the block partials: sums3 (dev, 3 floats) = sum r^2, sum d^2, sum u_free^2 */
+int pf_local_sums(const pf_problem* p, float* sums3, void* stream);
+/* grad_u[shared_dof] = iface[slot] (the all-reduced interface gradient) */
+int pf_iface_unpack(const pf_problem* p, const float* iface, float* vec, void* stream);
+/* optimizer_u.step() + BC clamp + sum u_free^2 partials from p->grad_u (solver.py:292,297-298,304) */
+int pf_adam_u(const pf_problem* p, void* stream);
+/* optimizer_theta.step() from p->grad_theta (already reduced over ranks) + padded image refresh */
+int pf_adam_theta(const pf_problem* p, void* stream);
+/* monitors/history/stop test from globally reduced sums: sums_r2d2 (dev, 2 floats: sum r^2, sum d^2)
+ * and sum_u2 (dev, 1 float) */
+int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* sum_u2, void* stream);
 
 /* ---- extensions (off the default path) ------------------------------------------------ */
 /* generic Adam (torch.optim.Adam single-tensor arithmetic) on a flat vector */

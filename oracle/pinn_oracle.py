@@ -314,6 +314,28 @@ def loss_and_grads(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
                    grad_theta=grad_theta, stiffness=s, young=e_val, area=a_val)
 
 
+def vjp_internal_force(pb: Problem, geo: Geometry, u: np.ndarray, lam: float, g_f: np.ndarray,
+                       fe_mode: str = "reference"):
+    """(K^T g_f, d<g_f, f_int>/dtheta) for an arbitrary upstream gradient g_f (n_dofs,): the part of
+    loss.backward() (solver.py:289) that goes through assemble_system_torch.  Used by the sharded
+    driver tests, where g_f on shared dofs comes from another rank."""
+    u = u.astype(f32)
+    s, e_val, a_val, e_ctx, a_ctx = element_stiffness(pb, geo, lam)
+    g_fe = g_f.astype(f32)[geo.dofs]
+    grad_u = np.zeros(pb.ndof, dtype=f32)
+    np.add.at(grad_u, geo.dofs.reshape(-1), ke_times(geo, s, g_fe, fe_mode).reshape(-1))
+    pu = ke_times(geo, np.ones_like(s), u[geo.dofs], fe_mode)
+    g_ea = (np.sum(g_fe * pu, axis=1, dtype=f32) / geo.l0).astype(f32)
+    grad_theta: List[Optional[np.ndarray]] = []
+    for prop, ctx, other in ((pb.young, e_ctx, a_val), (pb.area, a_ctx, e_val)):
+        if isinstance(prop, NetParams):
+            z, acts = ctx
+            g_out = (g_ea * other * f32(prop.scale)).astype(f32)
+            g_z = (g_out * softplus_grad(z)).astype(f32) if prop.enforce_positive else g_out
+            grad_theta.extend(mlp_backward(prop, acts, g_z))
+    return grad_u, grad_theta
+
+
 def dense_stiffness(pb: Problem, geo: Geometry, lam: float) -> np.ndarray:
     """k_global of assemble_system_torch (nn_assembly.py:228-229); small ndof only."""
     s, *_ = element_stiffness(pb, geo, lam)

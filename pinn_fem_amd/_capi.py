@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpinnfem_hip.so")
 
 PF_ABI_VERSION = 1
 PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
-PF_DOF_FIXED, PF_DOF_MEASURED = 1, 2
+PF_DOF_FIXED, PF_DOF_MEASURED, PF_DOF_SHARED, PF_DOF_GHOST = 1, 2, 4, 8
 PF_WG_SHUFFLE, PF_WG_MFMA = 0, 1
 PF_FE_REFERENCE, PF_FE_DELTA = 0, 1
 PF_HIST_COLS = 6
@@ -74,6 +74,8 @@ class PfProblem(C.Structure):
         ("n_part_blocks", C.c_int32), ("pad_total", C.c_int32),
         ("pad_index", C.c_void_p),
         ("n_meas_f", C.c_float), ("fe_mode", C.c_int32),
+        ("shared_dofs", C.c_void_p), ("shared_slot", C.c_void_p),
+        ("n_shared", C.c_int32), ("n_iface", C.c_int32),
     ]
 
 
@@ -101,6 +103,13 @@ SYMBOLS = {
     "pf_gd_iterations": (C.c_int, [_PP, C.c_int, C.c_void_p]),
     "pf_gd_iterations_timed": (C.c_int, [_PP, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "pf_loss_and_grads": (C.c_int, [_PP, C.c_void_p]),
+    "pf_iface_pack": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_iface_unpack": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_iface_fix_residual": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
+    "pf_local_sums": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
+    "pf_adam_u": (C.c_int, [_PP, C.c_void_p]),
+    "pf_adam_theta": (C.c_int, [_PP, C.c_void_p]),
+    "pf_finalize_from": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pf_diag_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),

@@ -10,12 +10,20 @@ int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s);
 int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s);
 int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s);
 int pf_launch_pack_theta(const pf_problem* p, hipStream_t s);
-int pf_launch_finalize(const pf_problem* p, int mode, hipStream_t s);
+int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s);
+int pf_launch_theta_stage1(const pf_problem* p, hipStream_t s);
 int pf_launch_reset(const pf_problem* p, hipStream_t s);
 int pf_launch_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,
                    double beta1, double beta2, double eps, hipStream_t s);
 int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s);
 int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s);
+int pf_launch_iface_pack(const pf_problem* p, const float* vec, float* iface, hipStream_t s);
+int pf_launch_iface_unpack(const pf_problem* p, const float* iface, float* vec, hipStream_t s);
+int pf_launch_iface_fix_residual(const pf_problem* p, const float* iface, hipStream_t s);
+int pf_launch_local_sums(const pf_problem* p, float* sums3, hipStream_t s);
+int pf_launch_adam_u(const pf_problem* p, hipStream_t s);
+int pf_launch_adam_theta(const pf_problem* p, hipStream_t s);
+int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, hipStream_t s);
 
 static thread_local char g_err[512] = "";
 
@@ -156,7 +164,7 @@ int pf_net_pad_index(int in_dim, int width, int n_hidden, int local) {
 
 long long pf_partials_count(const pf_problem* p) {
   if (!p) return PF_ERR_ARG;
-  return (long long)PF_PART_WG + (long long)p->n_part_blocks * (long long)p->pad_total;
+  return (long long)PF_PART_WG + ((long long)p->n_part_blocks + PF_RG) * (long long)p->pad_total;
 }
 
 int pf_pack_theta(const pf_problem* p, void* stream) {
@@ -228,7 +236,7 @@ int pf_theta_reduce(const pf_problem* p, int fuse_adam, void* stream) {
 int pf_finalize(const pf_problem* p, void* stream) {
   int rc = check_problem(p);
   if (rc) return rc;
-  PF_TRY(pf_launch_finalize(p, 0, (hipStream_t)stream), "pf_finalize");
+  PF_TRY(pf_launch_finalize(p, 0, 0, (hipStream_t)stream), "pf_finalize");
   return PF_OK;
 }
 
@@ -264,9 +272,9 @@ static int enqueue_iteration(const pf_problem* p, int fuse_adam, int finalize_mo
   PF_MARK(K_GRADU);
   PF_TRY(pf_launch_node_gradu(p, fuse_adam, s), "node_gradu");
   PF_MARK(K_THETA);
-  if (any_net) PF_TRY(pf_launch_theta_reduce(p, fuse_adam, s), "theta_reduce");
+  if (any_net) PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
   PF_MARK(K_FINALIZE);
-  PF_TRY(pf_launch_finalize(p, finalize_mode, s), "finalize");
+  PF_TRY(pf_launch_finalize(p, finalize_mode, any_net ? 1 : 0, s), "finalize");
   PF_MARK(K_COUNT);
 #undef PF_MARK
   return PF_OK;
@@ -327,6 +335,72 @@ int pf_loss_and_grads(const pf_problem* p, void* stream) {
   if (rc) return rc;
   if (!p->grad_u) return fail(PF_ERR_ARG, "grad_u required");
   return enqueue_iteration(p, 0, 1, (hipStream_t)stream, nullptr);
+}
+
+static int check_shared(const pf_problem* p) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (p->n_shared < 0 || p->n_iface < p->n_shared) return fail(PF_ERR_ARG, "bad interface sizes");
+  if (p->n_shared > 0 && (!p->shared_dofs || !p->shared_slot)) return fail(PF_ERR_ARG, "null interface maps");
+  if (pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks) >= PF_MAX_BLOCKS)
+    return fail(PF_ERR_ARG, "multi-GPU needs n_part_blocks < PF_MAX_BLOCKS (one slot is reserved)");
+  return PF_OK;
+}
+
+int pf_iface_pack(const pf_problem* p, const float* vec, float* iface, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!vec || !iface) return fail(PF_ERR_ARG, "null vec / iface");
+  PF_TRY(pf_launch_iface_pack(p, vec, iface, (hipStream_t)stream), "pf_iface_pack");
+  return PF_OK;
+}
+
+int pf_iface_unpack(const pf_problem* p, const float* iface, float* vec, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!vec || !iface) return fail(PF_ERR_ARG, "null vec / iface");
+  PF_TRY(pf_launch_iface_unpack(p, iface, vec, (hipStream_t)stream), "pf_iface_unpack");
+  return PF_OK;
+}
+
+int pf_iface_fix_residual(const pf_problem* p, const float* iface, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!iface) return fail(PF_ERR_ARG, "null iface");
+  PF_TRY(pf_launch_iface_fix_residual(p, iface, (hipStream_t)stream), "pf_iface_fix_residual");
+  return PF_OK;
+}
+
+int pf_local_sums(const pf_problem* p, float* sums3, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!sums3) return fail(PF_ERR_ARG, "null sums3");
+  PF_TRY(pf_launch_local_sums(p, sums3, (hipStream_t)stream), "pf_local_sums");
+  return PF_OK;
+}
+
+int pf_adam_u(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!p->grad_u || !p->m_u || !p->v_u) return fail(PF_ERR_ARG, "pf_adam_u: null grad_u / moments");
+  PF_TRY(pf_launch_adam_u(p, (hipStream_t)stream), "pf_adam_u");
+  return PF_OK;
+}
+
+int pf_adam_theta(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (p->n_theta_active > 0 && (!p->m_t || !p->v_t)) return fail(PF_ERR_ARG, "null Adam moments for theta");
+  PF_TRY(pf_launch_adam_theta(p, (hipStream_t)stream), "pf_adam_theta");
+  return PF_OK;
+}
+
+int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* sum_u2, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!sums_r2d2 || !sum_u2) return fail(PF_ERR_ARG, "null sums");
+  PF_TRY(pf_launch_finalize_from(p, sums_r2d2, sum_u2, (hipStream_t)stream), "pf_finalize_from");
+  return PF_OK;
 }
 
 int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,

@@ -13,6 +13,8 @@
 #define PF_PART_D2 (PF_MAX_BLOCKS)
 #define PF_PART_U2 (2 * PF_MAX_BLOCKS)
 #define PF_PART_WG (3 * PF_MAX_BLOCKS)
+// after the [n_part_blocks][pad_total] rows: [PF_RG][pad_total] second-level partial rows
+#define PF_RG 16
 
 // elements per block-iteration of the net kernels (2 waves)
 #define PF_NET_THREADS 128

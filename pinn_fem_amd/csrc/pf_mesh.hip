@@ -124,13 +124,15 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_residual(pf_problem P,
       if (!compute_loss) continue;
       const unsigned fl = M.dof_flags[dof];
       float gf = 0.f;
+      // shared dofs (multi-GPU): f_int is still partial here; pf_iface_fix_residual redoes them
+      const bool mine = !(fl & PF_DOF_SHARED);
       if (!(fl & PF_DOF_FIXED)) {
         const float r = f[c] - P.lam * M.f_ext[dof];  // solver.py:267-269
-        sum_r2 += r * r;
+        if (mine) sum_r2 += r * r;
         gf = P.alpha_physics * r;                     // d(alpha_p * 0.5*sum r^2)/dr
       }
       P.g_f[dof] = gf;
-      if (P.use_data && (fl & PF_DOF_MEASURED)) {
+      if (mine && P.use_data && (fl & PF_DOF_MEASURED)) {
         const float d = M.meas_val[dof] - P.u[dof];   // solver.py:274
         sum_d2 += d * d;
       }
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P) {
         const float denom = sqrtf(v) / bc2s + eps;
         uo = uo + (-step_size) * (m / denom);         // addcdiv_
         if (fl & PF_DOF_FIXED) uo = 0.f;              // solver.py:297-298 (moments keep evolving)
-        else sum_u2 += uo * uo;
+        else if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
         P.m_u[dof] = m;
         P.v_u[dof] = v;
         P.u[dof] = uo;
@@ -219,37 +221,61 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P) {
 }
 
 // ---- parameter gradient: sum block partials (fixed order) -> torch layout (+ Adam on theta) --------
-__global__ __launch_bounds__(256) void k_theta_reduce(pf_problem P, int nb_rows, int fuse_adam) {
+// stage 1: [nb_rows][pad_total] -> [PF_RG][pad_total]; grid (ceil(pad_total/64), PF_RG), 256 threads =
+// 64 columns x 4 row lanes, every thread a short strided row sum, then a fixed-order LDS combine.
+__global__ __launch_bounds__(256) void k_theta_stage1(pf_problem P, int nb_rows) {
   if (P.state->done) return;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= P.n_theta_active) return;
-  const int pi = P.pad_index[q];
-  const float* __restrict__ rows = P.partials + PF_PART_WG + pi;
-  float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= nb_rows; b += 4) {
-    g0 += rows[(size_t)(b + 0) * P.pad_total];
-    g1 += rows[(size_t)(b + 1) * P.pad_total];
-    g2 += rows[(size_t)(b + 2) * P.pad_total];
-    g3 += rows[(size_t)(b + 3) * P.pad_total];
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  const int rpg = (nb_rows + PF_RG - 1) / PF_RG;
+  const int r0 = blockIdx.y * rpg, r1 = min(r0 + rpg, nb_rows);
+  float a = 0.f;
+  if (col < P.pad_total) {
+    const float* __restrict__ rows = P.partials + PF_PART_WG + col;
+    for (int r = r0 + rl; r < r1; r += 4) a += rows[(size_t)r * P.pad_total];
   }
-  for (; b < nb_rows; ++b) g0 += rows[(size_t)b * P.pad_total];
-  const float g = (g0 + g1) + (g2 + g3);
-  P.grad_theta[q] = g;
-  if (fuse_adam) {
-    const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
-    const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
-    float m = P.m_t[q], v = P.v_t[q], th = P.theta[q];
-    m = m + b1w * (g - m);
-    v = v * b2;
-    v = v + (b2w * g) * g;
-    const float denom = sqrtf(v) / bc2s + (float)P.eps;
-    th = th + (-step_size) * (m / denom);
-    P.m_t[q] = m;
-    P.v_t[q] = v;
-    P.theta[q] = th;
-    P.theta_pad[pi] = th;
+  red[rl][cl] = a;
+  __syncthreads();
+  if (rl == 0 && col < P.pad_total) {
+    const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    P.partials[PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total + (size_t)blockIdx.y * P.pad_total + col] = t;
   }
+}
+
+// stage 2 (device function, one block): PF_RG partial rows -> grad_theta[q] (+ Adam, refreshed padded
+// image).  new_theta (LDS, n_theta_active floats) receives the updated parameters when non-null.
+__device__ __forceinline__ void theta_stage2(const pf_problem& P, int fuse_adam, float* new_theta) {
+  const float* __restrict__ p2 = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total;
+  const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
+  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
+  const float eps = (float)P.eps;
+  for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
+    const int pi = P.pad_index[q];
+    float g = 0.f;
+#pragma unroll
+    for (int r = 0; r < PF_RG; ++r) g += p2[(size_t)r * P.pad_total + pi];
+    P.grad_theta[q] = g;
+    float th = P.theta[q];
+    if (fuse_adam) {
+      float m = P.m_t[q], v = P.v_t[q];
+      m = m + b1w * (g - m);
+      v = v * b2;
+      v = v + (b2w * g) * g;
+      const float denom = sqrtf(v) / bc2s + eps;
+      th = th + (-step_size) * (m / denom);
+      P.m_t[q] = m;
+      P.v_t[q] = v;
+      P.theta[q] = th;
+      P.theta_pad[pi] = th;
+    }
+    if (new_theta) new_theta[q] = th;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_theta_stage2(pf_problem P, int fuse_adam) {
+  if (P.state->done) return;
+  theta_stage2(P, fuse_adam, nullptr);
 }
 
 __global__ void k_pack_theta(pf_problem P) {
@@ -257,13 +283,16 @@ __global__ void k_pack_theta(pf_problem P) {
   if (q < P.n_theta_active) P.theta_pad[P.pad_index[q]] = P.theta[q];
 }
 
-// ---- monitors / history / stop test / next Adam scalars -----------------------------------------
-// mode 0: full iteration bookkeeping; mode 1: losses only (autograd binding)
-__global__ __launch_bounds__(256) void k_finalize(pf_problem P, int nb_node, int mode) {
+// ---- parameter update + monitors / history / stop test / next Adam scalars ------------------------
+// mode 0: full iteration bookkeeping incl. theta stage 2 + Adam (solver.py:293-294, 304-355);
+// mode 1: losses + gradient reduction only (autograd binding).  One block of 1024 threads.
+__global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, int mode, int with_theta) {
   pf_state* S = P.state;
   if (S->done) return;
-  __shared__ double dred[8];
-  __shared__ float fred[16];
+  extern __shared__ float new_theta[];  // n_theta_active floats
+  __shared__ double dred[16];
+  __shared__ float wnorm[16];
+  if (with_theta) theta_stage2(P, mode == 0, new_theta);
   double a = 0.0, b = 0.0, c = 0.0;
   for (int i = threadIdx.x; i < nb_node; i += blockDim.x) {
     a += (double)P.partials[PF_PART_R2 + i];
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(256) void k_finalize(pf_problem P, int nb_node, int
   }
   const float sum_r2 = (float)pf_block_sum_d(a, dred);
   const float sum_d2 = (float)pf_block_sum_d(b, dred);
-  const float sum_u2 = (float)pf_block_sum_d(c, dred);
+  const float sum_u2 = (float)pf_block_sum_d(c, dred);   // (also orders new_theta writes before reads)
   const float loss_p = 0.5f * sum_r2;                                   // solver.py:270
   float loss_d = 0.f, loss;
   if (P.use_data) {
@@ -283,17 +312,24 @@ __global__ __launch_bounds__(256) void k_finalize(pf_problem P, int nb_node, int
   }
   const float rn = sqrtf(sum_r2);                                       // torch.norm :306
   // theta_norm = sum_k ||theta_k||_2 over ALL parameter tensors (density included) :319
+  // wave w owns tensors w, w+16, ...; fixed order -> reproducible
   double tn = 0.0;
-  if (mode == 0) {
-    for (int t = 0; t < P.n_tensors; ++t) {
+  if (mode == 0 && P.n_tensors > 0) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float wsum = 0.f;
+    for (int t = wv; t < P.n_tensors; t += 16) {
       const int lo = P.tensor_off[t], hi = P.tensor_off[t + 1];
       float s = 0.f;
-      for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        const float x = P.theta[i];
+      for (int i = lo + lane; i < hi; i += 64) {
+        const float x = (with_theta && i < P.n_theta_active) ? new_theta[i] : P.theta[i];
         s += x * x;
       }
-      tn += (double)sqrtf(pf_block_sum(s, fred));
+      wsum += sqrtf(pf_wave_sum(s));
     }
+    if (lane == 0) wnorm[wv] = wsum;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int w = 0; w < 16; ++w) tn += (double)wnorm[w];
   }
   if (threadIdx.x != 0) return;
   S->loss_total = loss;
@@ -323,6 +359,118 @@ __global__ __launch_bounds__(256) void k_finalize(pf_problem P, int nb_node, int
   S->step_size_u = (float)((double)P.lr_u / bc1);
   S->step_size_t = (float)((double)P.lr_t / bc1);
   S->bc2_sqrt = (float)sqrt(bc2);
+}
+
+// ---- multi-GPU shard interface -------------------------------------------------------------------
+__global__ void k_iface_pack(pf_problem P, const float* __restrict__ vec, float* __restrict__ iface) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < P.n_shared) iface[P.shared_slot[k]] = vec[P.shared_dofs[k]];
+}
+
+__global__ void k_iface_unpack(pf_problem P, const float* __restrict__ iface, float* __restrict__ vec) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < P.n_shared) vec[P.shared_dofs[k]] = iface[P.shared_slot[k]];
+}
+
+// one block; the extra partial slot sits right after the node kernels' block partials
+__global__ __launch_bounds__(256) void k_iface_fix_residual(pf_problem P, const float* __restrict__ iface,
+                                                             int slot) {
+  if (P.state->done) return;
+  __shared__ float red[16];
+  const pf_mesh& M = P.mesh;
+  float sum_r2 = 0.f, sum_d2 = 0.f;
+  for (int k = threadIdx.x; k < P.n_shared; k += blockDim.x) {
+    const int dof = P.shared_dofs[k];
+    const unsigned fl = M.dof_flags[dof];
+    const bool owner = !(fl & PF_DOF_GHOST);
+    float gf = 0.f;
+    if (!(fl & PF_DOF_FIXED)) {
+      const float r = iface[P.shared_slot[k]] - P.lam * M.f_ext[dof];
+      if (owner) sum_r2 += r * r;
+      gf = P.alpha_physics * r;
+    }
+    P.g_f[dof] = gf;
+    if (owner && P.use_data && (fl & PF_DOF_MEASURED)) {
+      const float d = M.meas_val[dof] - P.u[dof];
+      sum_d2 += d * d;
+    }
+  }
+  const float t0 = pf_block_sum(sum_r2, red);
+  const float t1 = pf_block_sum(sum_d2, red);
+  if (threadIdx.x == 0) {
+    P.partials[PF_PART_R2 + slot] = t0;
+    P.partials[PF_PART_D2 + slot] = t1;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_local_sums(pf_problem P, int nb, float* __restrict__ sums3) {
+  __shared__ double dred[16];
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+    a += (double)P.partials[PF_PART_R2 + i];
+    b += (double)P.partials[PF_PART_D2 + i];
+  }
+  const int nbu = nb - (P.n_shared > 0 ? 1 : 0);  // the u^2 partials have no interface slot
+  for (int i = threadIdx.x; i < nbu; i += blockDim.x) c += (double)P.partials[PF_PART_U2 + i];
+  const double ta = pf_block_sum_d(a, dred), tb = pf_block_sum_d(b, dred), tc = pf_block_sum_d(c, dred);
+  if (threadIdx.x == 0) { sums3[0] = (float)ta; sums3[1] = (float)tb; sums3[2] = (float)tc; }
+}
+
+// Adam on u from a given gradient + clamp + ||u_free||^2 partials (owned dofs only)
+__global__ __launch_bounds__(PF_NODE_THREADS) void k_adam_u(pf_problem P) {
+  if (P.state->done) return;
+  __shared__ float red[16];
+  const pf_mesh& M = P.mesh;
+  const float step_size = P.state->step_size_u, bc2s = P.state->bc2_sqrt;
+  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
+  const float eps = (float)P.eps;
+  float sum_u2 = 0.f;
+  for (int dof = blockIdx.x * blockDim.x + threadIdx.x; dof < M.n_dofs; dof += gridDim.x * blockDim.x) {
+    const unsigned fl = M.dof_flags[dof];
+    const float gu = P.grad_u[dof];
+    float m = P.m_u[dof], v = P.v_u[dof], uo = P.u[dof];
+    m = m + b1w * (gu - m);
+    v = v * b2;
+    v = v + (b2w * gu) * gu;
+    const float denom = sqrtf(v) / bc2s + eps;
+    uo = uo + (-step_size) * (m / denom);
+    if (fl & PF_DOF_FIXED) uo = 0.f;
+    else if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
+    P.m_u[dof] = m;
+    P.v_u[dof] = v;
+    P.u[dof] = uo;
+  }
+  const float t = pf_block_sum(sum_u2, red);
+  if (threadIdx.x == 0) P.partials[PF_PART_U2 + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(1024) void k_adam_theta(pf_problem P) {
+  if (P.state->done) return;
+  const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
+  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
+  const float eps = (float)P.eps;
+  for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
+    const float g = P.grad_theta[q];
+    float m = P.m_t[q], v = P.v_t[q], th = P.theta[q];
+    m = m + b1w * (g - m);
+    v = v * b2;
+    v = v + (b2w * g) * g;
+    const float denom = sqrtf(v) / bc2s + eps;
+    th = th + (-step_size) * (m / denom);
+    P.m_t[q] = m;
+    P.v_t[q] = v;
+    P.theta[q] = th;
+    P.theta_pad[P.pad_index[q]] = th;
+  }
+}
+
+// copy globally reduced sums into partial slot 0 so that k_finalize(nb_node = 1) consumes them
+__global__ void k_store_sums(pf_problem P, const float* __restrict__ rd, const float* __restrict__ u2) {
+  if (threadIdx.x == 0) {
+    P.partials[PF_PART_R2] = rd[0];
+    P.partials[PF_PART_D2] = rd[1];
+    P.partials[PF_PART_U2] = u2[0];
+  }
 }
 
 __global__ void k_reset(pf_problem P) {
@@ -443,11 +591,18 @@ int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s) {
   return PF_CHECK_LAUNCH();
 }
 
-int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s) {
+int pf_launch_theta_stage1(const pf_problem* p, hipStream_t s) {
   if (p->n_theta_active <= 0) return PF_OK;
   const int nb_rows = pf_net_blocks(p->mesh.n_elems, p->n_part_blocks);
-  const int nb = (p->n_theta_active + 255) / 256;
-  hipLaunchKernelGGL(k_theta_reduce, dim3(nb), dim3(256), 0, s, *p, nb_rows, fuse_adam);
+  hipLaunchKernelGGL(k_theta_stage1, dim3((p->pad_total + 63) / 64, PF_RG), dim3(256), 0, s, *p, nb_rows);
+  return PF_CHECK_LAUNCH();
+}
+
+int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s) {
+  if (p->n_theta_active <= 0) return PF_OK;
+  int rc = pf_launch_theta_stage1(p, s);
+  if (rc != PF_OK) return rc;
+  hipLaunchKernelGGL(k_theta_stage2, dim3(1), dim3(1024), 0, s, *p, fuse_adam);
   return PF_CHECK_LAUNCH();
 }
 
@@ -458,9 +613,16 @@ int pf_launch_pack_theta(const pf_problem* p, hipStream_t s) {
   return PF_CHECK_LAUNCH();
 }
 
-int pf_launch_finalize(const pf_problem* p, int mode, hipStream_t s) {
+// with_theta: also run theta stage 2 (+Adam in mode 0) inside the finalize block
+int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s) {
   const int nb_node = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, *p, nb_node, mode);
+  const int wt = with_theta && p->n_theta_active > 0;
+  const size_t lds = wt ? (size_t)p->n_theta_active * sizeof(float) : 0;
+  if (lds > 60000) {
+    pf_set_error("too many trainable parameters for the fused finalize kernel");
+    return PF_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), lds, s, *p, nb_node, mode, wt);
   return PF_CHECK_LAUNCH();
 }
 
@@ -491,5 +653,43 @@ int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s) {
 int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s) {
   if (p->mesh.dim == 2) hipLaunchKernelGGL(k_dense_k<2>, dim3(1), dim3(64), 0, s, *p, K);
   else hipLaunchKernelGGL(k_dense_k<1>, dim3(1), dim3(64), 0, s, *p, K);
+  return PF_CHECK_LAUNCH();
+}
+
+// ---- multi-GPU launchers ---------------------------------------------------------------------------
+int pf_launch_iface_pack(const pf_problem* p, const float* vec, float* iface, hipStream_t s) {
+  if (hipMemsetAsync(iface, 0, (size_t)p->n_iface * sizeof(float), s) != hipSuccess) return PF_ERR_HIP;
+  if (p->n_shared > 0)
+    hipLaunchKernelGGL(k_iface_pack, dim3((p->n_shared + 255) / 256), dim3(256), 0, s, *p, vec, iface);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_iface_unpack(const pf_problem* p, const float* iface, float* vec, hipStream_t s) {
+  if (p->n_shared > 0)
+    hipLaunchKernelGGL(k_iface_unpack, dim3((p->n_shared + 255) / 256), dim3(256), 0, s, *p, iface, vec);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_iface_fix_residual(const pf_problem* p, const float* iface, hipStream_t s) {
+  const int slot = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks);
+  hipLaunchKernelGGL(k_iface_fix_residual, dim3(1), dim3(256), 0, s, *p, iface, slot);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_local_sums(const pf_problem* p, float* sums3, hipStream_t s) {
+  const int nb = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks) + (p->n_shared > 0 ? 1 : 0);
+  hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(1024), 0, s, *p, nb, sums3);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_adam_u(const pf_problem* p, hipStream_t s) {
+  const int nb = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks);
+  hipLaunchKernelGGL(k_adam_u, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_adam_theta(const pf_problem* p, hipStream_t s) {
+  if (p->n_theta_active <= 0) return PF_OK;
+  hipLaunchKernelGGL(k_adam_theta, dim3(1), dim3(1024), 0, s, *p);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, hipStream_t s) {
+  hipLaunchKernelGGL(k_store_sums, dim3(1), dim3(64), 0, s, *p, rd, u2);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, *p, 1, 0, 0);
   return PF_CHECK_LAUNCH();
 }

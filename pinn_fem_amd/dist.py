@@ -1,0 +1,395 @@
+"""Multi-GPU: elements sharded across ranks, one process per GPU, torch.distributed (RCCL over xGMI).
+
+The reference is single-process (no collectives, no devices); this module is the
+build's answer to BASELINE.json's "shard elements across the 8 GPUs of one node".
+
+Partition: contiguous element ranges.  A node whose elements live on several ranks is SHARED; every
+sharing rank keeps a copy of its u and Adam state, and the lowest sharing rank OWNS it (counts it in
+global sums, adds its data-loss term).  Per GD iteration there are three small all-reduces:
+  (1) interface vector of partial f_int          -> every sharing rank has the full f_int / residual
+  (2) [interface grad_u | grad_theta | sum r^2, sum d^2]
+  (3) sum u_free^2                                (monitor only)
+Everything else (u, f_int, Adam-u state, residual) stays sharded; theta and its Adam state are
+replicated and stay bit-identical because every rank applies the same reduced gradient.
+For a 1-D chain cut into G shards the interface has 2(G-1) dofs, so the traffic is ~4 kB per
+iteration regardless of N — latency-bound, as SURVEY.md §5/§8(e) predicts.
+
+The iteration driver (`run_iterations`) only talks to a ShardBackend; the product backend is
+HipShardBackend (HIP kernels).  Tests drive the same driver with an oracle-backed backend over gloo.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _capi
+from .plan import HostPlan, build_host_plan
+
+
+# ---------------------------------------------------------------------------------------------------
+# partition (host logic, numpy)
+# ---------------------------------------------------------------------------------------------------
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    elem_lo: int
+    elem_hi: int
+    nodes_global: np.ndarray     # global node id of each local node (ascending)
+    elements_local: np.ndarray   # (n_local_elems, 2) in local node numbering
+    shared_dofs: np.ndarray      # local dof indices shared with other ranks (ascending global dof)
+    shared_slot: np.ndarray      # their positions in the global interface vector
+    ghost_mask: np.ndarray       # bool per local dof: shared and owned by a lower rank
+    n_iface: int
+    dim: int
+
+
+def element_ranges(n_elems: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced element ranges [lo, hi) per rank."""
+    base, rem = divmod(n_elems, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def partition_mesh(elements: np.ndarray, n_nodes: int, dim: int, rank: int, world: int) -> Shard:
+    """Deterministic on every rank (same inputs -> same interface numbering)."""
+    elements = np.asarray(elements, dtype=np.int64)
+    n_elems = elements.shape[0]
+    ranges = element_ranges(n_elems, world)
+    erank = np.empty(n_elems, dtype=np.int64)
+    for r, (lo, hi) in enumerate(ranges):
+        erank[lo:hi] = r
+    rmin = np.full(n_nodes, world, dtype=np.int64)
+    rmax = np.full(n_nodes, -1, dtype=np.int64)
+    for col in range(2):
+        np.minimum.at(rmin, elements[:, col], erank)
+        np.maximum.at(rmax, elements[:, col], erank)
+    shared_nodes = np.flatnonzero((rmax > rmin) & (rmax >= 0))       # ascending global id
+    lo, hi = ranges[rank]
+    loc = elements[lo:hi]
+    nodes_global = np.unique(loc.reshape(-1)) if loc.size else np.zeros(0, dtype=np.int64)
+    elements_local = np.searchsorted(nodes_global, loc) if loc.size else np.zeros((0, 2), dtype=np.int64)
+    # interface numbering: shared node k -> slots k*dim .. k*dim+dim-1
+    mine = np.isin(shared_nodes, nodes_global)
+    my_shared_nodes = shared_nodes[mine]
+    k_idx = np.flatnonzero(mine)
+    local_idx = np.searchsorted(nodes_global, my_shared_nodes)
+    comp = np.arange(dim)
+    shared_dofs = (local_idx[:, None] * dim + comp[None, :]).reshape(-1)
+    shared_slot = (k_idx[:, None] * dim + comp[None, :]).reshape(-1)
+    ghost = np.zeros(len(nodes_global) * dim, dtype=bool)
+    not_owner = rmin[my_shared_nodes] != rank
+    ghost_nodes = local_idx[not_owner]
+    if ghost_nodes.size:
+        ghost[(ghost_nodes[:, None] * dim + comp[None, :]).reshape(-1)] = True
+    return Shard(rank=rank, world=world, elem_lo=lo, elem_hi=hi, nodes_global=nodes_global,
+                 elements_local=elements_local, shared_dofs=shared_dofs.astype(np.int32),
+                 shared_slot=shared_slot.astype(np.int32), ghost_mask=ghost,
+                 n_iface=int(len(shared_nodes) * dim), dim=dim)
+
+
+def shard_host_plan(shard: Shard, nodes, loads, fixed_dofs, measured_disp, measured_dofs,
+                    n_dofs_global: int) -> Tuple[HostPlan, int]:
+    """Local HostPlan (local numbering) + the global measurement count."""
+    dim = shard.dim
+    ng = shard.nodes_global
+    nodes = np.asarray(nodes, dtype=float)
+    nodes_l = nodes[ng]
+    comp = np.arange(dim)
+    dofs_g = (ng[:, None] * dim + comp[None, :]).reshape(-1)            # global dof of each local dof
+    loads_l = np.asarray(loads, dtype=float).reshape(-1)[dofs_g]
+    g2l = -np.ones(n_dofs_global, dtype=np.int64)
+    g2l[dofs_g] = np.arange(dofs_g.size)
+    fixed_g = np.asarray(fixed_dofs, dtype=np.int64).reshape(-1)
+    fixed_l = g2l[fixed_g]
+    fixed_l = fixed_l[fixed_l >= 0]
+    mv_l = md_l = None
+    n_meas_global = 0
+    if measured_disp is not None and measured_dofs is not None:
+        md_g = np.asarray(measured_dofs, dtype=np.int64).reshape(-1)
+        mv_g = np.asarray(measured_disp, dtype=float).reshape(-1)
+        n_meas_global = int(md_g.size)
+        md_loc = g2l[md_g]
+        keep = md_loc >= 0
+        keep[keep] &= ~shard.ghost_mask[md_loc[keep]]                  # the owner adds the data term
+        md_l, mv_l = md_loc[keep], mv_g[keep]
+    hp = build_host_plan(nodes_l, shard.elements_local, loads_l, fixed_l, dim, mv_l, md_l)
+    hp.dof_flags[shard.shared_dofs] |= _capi.PF_DOF_SHARED
+    hp.dof_flags[shard.ghost_mask] |= _capi.PF_DOF_GHOST
+    hp.n_meas = n_meas_global
+    return hp, n_meas_global
+
+
+# ---------------------------------------------------------------------------------------------------
+# iteration driver (backend-agnostic)
+# ---------------------------------------------------------------------------------------------------
+class ShardBackend:
+    """What the driver needs from one rank's local problem.  All tensors live on `device`."""
+    device: torch.device
+    n_iface: int
+    n_theta_active: int
+
+    def forward_residual(self): ...            # nets forward + local partial f_int (+ local losses)
+    def pack_f(self, iface: torch.Tensor): ...            # iface[slot] = partial f_int (else 0)
+    def fix_residual(self, iface: torch.Tensor): ...      # full f_int on shared dofs -> residual
+    def backward(self, buf2: torch.Tensor): ...           # -> [iface grad_u | grad_theta | r2, d2, -]
+    def update(self, buf2: torch.Tensor, u2: torch.Tensor): ...  # Adam(u), Adam(theta); u2[2]=local sum
+    def finalize(self, r2d2: torch.Tensor, u2: torch.Tensor): ...
+
+
+def _all_reduce(t: torch.Tensor, group=None):
+    """Sum over ranks, in place.  RCCL reduces device tensors directly; with a gloo group (CPU tests,
+    or several ranks sharing one GPU in the single-GPU rehearsal) device tensors are staged through
+    the host."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, group=group)
+
+
+def run_iterations(backend: ShardBackend, n_iter: int, group=None,
+                   bufs: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
+    """n_iter GD iterations with the three collectives of the module docstring."""
+    if bufs is None:
+        bufs = make_buffers(backend)
+    if1, buf2, u2 = bufs
+    nt = backend.n_theta_active
+    for _ in range(n_iter):
+        backend.forward_residual()
+        backend.pack_f(if1)
+        _all_reduce(if1, group)
+        backend.fix_residual(if1)
+        backend.backward(buf2)
+        _all_reduce(buf2, group)
+        backend.update(buf2, u2)
+        _all_reduce(u2, group)
+        backend.finalize(buf2[backend.n_iface + nt:backend.n_iface + nt + 2], u2[2:3])
+    return bufs
+
+
+def make_buffers(backend: ShardBackend):
+    dev = backend.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    # buf2 = [interface grad_u | grad_theta | sum r^2, sum d^2, (unused)] ; u2 = [-, -, sum u_free^2]
+    return (torch.zeros(max(backend.n_iface, 1), **f32),
+            torch.zeros(backend.n_iface + backend.n_theta_active + 3, **f32),
+            torch.zeros(3, **f32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# HIP backend
+# ---------------------------------------------------------------------------------------------------
+class HipShardBackend(ShardBackend):
+    """One rank's shard on its GPU: a HipEngine over the local sub-mesh plus the interface maps."""
+
+    def __init__(self, local_model, host_plan: HostPlan, shard: Shard, has_measurements: bool,
+                 device=None, wg_mode=None, fe_mode=None):
+        from .engine import HipEngine
+        self.shard = shard
+        self.eng = HipEngine(local_model, device=device, host_plan=host_plan, wg_mode=wg_mode,
+                             fe_mode=fe_mode, n_part_blocks=_capi.PF_MAX_BLOCKS - 1,
+                             iface=(shard.shared_dofs, shard.shared_slot, shard.n_iface))
+        self.eng.has_measurements = has_measurements
+        self.device = self.eng.device
+        self.n_iface = shard.n_iface
+        self.n_theta_active = self.eng.n_theta_active
+        self.fbuf = torch.zeros(host_plan.n_dofs, dtype=torch.float32, device=self.device)
+        self._buf2_ptr = None
+
+    # -- solve_gd-level control ---------------------------------------------------------------------
+    def begin(self, u_initial_local, lam, config, want_history=True):
+        self.eng.begin(u_initial_local, lam, config, want_history=want_history)
+        self.eng.P.grad_u = self.eng.grad_u.data_ptr()
+        self._buf2_ptr = None   # begin() re-pointed grad_theta at the engine's own buffer
+
+    def state(self):
+        return self.eng.state()
+
+    def history(self, n):
+        return self.eng.history(n)
+
+    # -- ShardBackend -------------------------------------------------------------------------------
+    def _call(self, fn, *args):
+        e = self.eng
+        _capi.check(fn(e._ref(), *args, e._stream()), fn.__name__ if hasattr(fn, "__name__") else "pf")
+
+    def forward_residual(self):
+        e, lib = self.eng, self.eng.lib
+        s, ref = e._stream(), e._ref()
+        for k, spec in enumerate(e.specs):
+            if spec.enabled:
+                _capi.check(lib.pf_net_forward(ref, k, s), "pf_net_forward")
+        _capi.check(lib.pf_node_residual(ref, self.fbuf.data_ptr(), s), "pf_node_residual")
+
+    def pack_f(self, iface):
+        e = self.eng
+        _capi.check(e.lib.pf_iface_pack(e._ref(), self.fbuf.data_ptr(), iface.data_ptr(), e._stream()),
+                    "pf_iface_pack")
+
+    def fix_residual(self, iface):
+        e = self.eng
+        _capi.check(e.lib.pf_iface_fix_residual(e._ref(), iface.data_ptr(), e._stream()),
+                    "pf_iface_fix_residual")
+
+    def backward(self, buf2):
+        e, lib = self.eng, self.eng.lib
+        s = e._stream()
+        # gradients of theta are reduced straight into the collective buffer
+        if self._buf2_ptr != buf2.data_ptr():
+            self._buf2_ptr = buf2.data_ptr()
+            e.P.grad_theta = buf2.data_ptr() + 4 * self.n_iface
+        ref = e._ref()
+        any_net = any(sp.enabled for sp in e.specs)
+        if any_net:
+            _capi.check(lib.pf_elem_adjoint(ref, s), "pf_elem_adjoint")
+            for k, spec in enumerate(e.specs):
+                if spec.enabled:
+                    _capi.check(lib.pf_net_backward(ref, k, s), "pf_net_backward")
+        _capi.check(lib.pf_node_gradu(ref, 0, s), "pf_node_gradu")
+        if any_net:
+            _capi.check(lib.pf_theta_reduce(ref, 0, s), "pf_theta_reduce")
+        _capi.check(lib.pf_iface_pack(ref, e.grad_u.data_ptr(), buf2.data_ptr(), s), "pf_iface_pack")
+        _capi.check(lib.pf_local_sums(ref, buf2.data_ptr() + 4 * (self.n_iface + self.n_theta_active), s),
+                    "pf_local_sums")
+
+    def update(self, buf2, u2):
+        e, lib = self.eng, self.eng.lib
+        s, ref = e._stream(), e._ref()
+        _capi.check(lib.pf_iface_unpack(ref, buf2.data_ptr(), e.grad_u.data_ptr(), s), "pf_iface_unpack")
+        _capi.check(lib.pf_adam_u(ref, s), "pf_adam_u")
+        _capi.check(lib.pf_adam_theta(ref, s), "pf_adam_theta")
+        _capi.check(lib.pf_local_sums(ref, u2.data_ptr(), s), "pf_local_sums")
+
+    def finalize(self, r2d2, u2):
+        e = self.eng
+        _capi.check(e.lib.pf_finalize_from(e._ref(), r2d2.data_ptr(), u2.data_ptr(), e._stream()),
+                    "pf_finalize_from")
+
+
+# ---------------------------------------------------------------------------------------------------
+# sharded solve_gd core (called by fem.solver.solve_gd when torch.distributed has world_size > 1)
+# ---------------------------------------------------------------------------------------------------
+def build_shard_backend(model, measured_disp, measured_dofs, rank: int, world: int, device=None,
+                        wg_mode=None, fe_mode=None) -> HipShardBackend:
+    from .fem.model import FEMModel
+    shard = partition_mesh(model.elements, model.nnode, model.dimension, rank, world)
+    has_meas = measured_disp is not None and measured_dofs is not None
+    hp, _ = shard_host_plan(shard, model.nodes, model.loads, model.fixed_dofs, measured_disp,
+                            measured_dofs, model.ndof)
+    dim = model.dimension
+    comp = np.arange(dim)
+    dofs_g = (shard.nodes_global[:, None] * dim + comp[None, :]).reshape(-1)
+    local_model = FEMModel(nodes=model.nodes[shard.nodes_global], elements=shard.elements_local,
+                           material=model.material, loads=model.loads[dofs_g],
+                           fixed_dofs=hp.fixed_dofs, dimension=dim)
+    be = HipShardBackend(local_model, hp, shard, has_meas, device=device, wg_mode=wg_mode, fe_mode=fe_mode)
+    be.dofs_global = dofs_g
+    return be
+
+
+def assembled_f_int(backend: "HipShardBackend", lam: float, group=None) -> torch.Tensor:
+    """Local view of the fully assembled f_int (re-evaluating the nets): partial gather + interface sum."""
+    e = backend.eng
+    f = e.internal_force(lam=lam)
+    iface = torch.zeros(max(backend.n_iface, 1), dtype=torch.float32, device=backend.device)
+    _capi.check(e.lib.pf_iface_pack(e._ref(), f.data_ptr(), iface.data_ptr(), e._stream()), "pf_iface_pack")
+    _all_reduce(iface, group)
+    _capi.check(e.lib.pf_iface_unpack(e._ref(), iface.data_ptr(), f.data_ptr(), e._stream()), "pf_iface_unpack")
+    return f
+
+
+def gather_global_vector(local: torch.Tensor, backend, n_dofs_global: int, group=None) -> np.ndarray:
+    """All ranks receive the full displacement vector (owned entries of every rank)."""
+    world = dist.get_world_size(group)
+    own = ~torch.from_numpy(backend.shard.ghost_mask)
+    idx = torch.from_numpy(backend.dofs_global)[own]
+    vals = local.detach().cpu()[own]
+    objs = [None] * world
+    dist.all_gather_object(objs, (idx.numpy(), vals.numpy()), group=group)
+    out = np.zeros(n_dofs_global, dtype=np.float32)
+    for i, v in objs:
+        out[i] = v
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench helper: weak-scaling chain, every rank builds only its own shard analytically
+# ---------------------------------------------------------------------------------------------------
+class ShardedChainEngine:
+    """Rank r owns elements [r*n, (r+1)*n) of a world*n-element collinear truss (SURVEY.md §8d
+    inputs).  Same kernels and collectives as the general path; no global arrays are built."""
+
+    def __init__(self, n_local: int, workload: str, rank: int, world: int, device):
+        from .fem.model import FEMModel, Material
+        from .fem.properties import NNProperty
+        from .nets import SimpleNN
+        n = int(n_local)
+        n_total = n * world
+        e0 = rank * n
+        x = (np.arange(n + 1, dtype=np.float64) + e0)
+        nodes_l = np.stack([x, np.zeros(n + 1)], axis=1)
+        el = np.stack([np.arange(n), np.arange(1, n + 1)], axis=1)
+        loads = np.zeros(2 * (n + 1))
+        if rank == world - 1:
+            loads[2 * n] = 1.0
+        fixed = list(2 * np.arange(n + 1) + 1)
+        if rank == 0:
+            fixed = [0] + fixed
+        fixed = np.array(sorted(fixed))
+        # shared nodes: global node r*n for r = 1..world-1  (local 0 of rank r, local n of rank r-1)
+        sd, ss = [], []
+        ghost = np.zeros(2 * (n + 1), dtype=bool)
+        if rank > 0:
+            sd += [0, 1]
+            ss += [2 * (rank - 1), 2 * (rank - 1) + 1]
+            ghost[0:2] = True                      # owned by rank-1
+        if rank < world - 1:
+            sd += [2 * n, 2 * n + 1]
+            ss += [2 * rank, 2 * rank + 1]
+        shard = Shard(rank=rank, world=world, elem_lo=e0, elem_hi=e0 + n,
+                      nodes_global=np.arange(e0, e0 + n + 1), elements_local=el,
+                      shared_dofs=np.array(sd, dtype=np.int32), shared_slot=np.array(ss, dtype=np.int32),
+                      ghost_mask=ghost, n_iface=2 * (world - 1), dim=2)
+        # measurements ux_i = x_i, uy_i = 0 at every global node >= 1 (owner adds the shared ones)
+        k = np.arange(n + 1)
+        keep = (k + e0 >= 1) & ~ghost[0::2]
+        kk = k[keep]
+        md = np.stack([2 * kk, 2 * kk + 1], axis=1).reshape(-1)
+        mv = np.stack([x[kk], np.zeros(kk.size)], axis=1).reshape(-1)
+        hp = build_host_plan(nodes_l, el, loads, fixed, 2, mv, md)
+        hp.dof_flags[shard.shared_dofs] |= _capi.PF_DOF_SHARED
+        hp.dof_flags[ghost] |= _capi.PF_DOF_GHOST
+        hp.n_meas = 2 * n_total
+        torch.manual_seed(0)                      # identical theta on every rank
+        widths = {"ex4": (20, 15, 10), "ex3": (20, None, None)}[workload]
+        props = [1.0 if w is None else NNProperty(SimpleNN(2, w, 3), input_dim=3, scale=1.0)
+                 for w in widths]
+        model = FEMModel(nodes=nodes_l, elements=el, material=Material(*props), loads=loads,
+                         fixed_dofs=fixed, dimension=2)
+        self.backend = HipShardBackend(model, hp, shard, True, device=device)
+        self.bufs = make_buffers(self.backend)
+
+    def begin(self, u0, lam, config):
+        self.backend.begin(u0, lam, config, want_history=False)
+
+    def iterate(self, n):
+        run_iterations(self.backend, n, bufs=self.bufs)
+
+    def iterate_timed(self, n):
+        """No per-kernel events in the sharded path (launches come from Python): returns zeros for the
+        kernel slots; bench.py still times the whole region."""
+        self.iterate(n)
+        return np.zeros(_capi.PF_KERNEL_SLOTS)
+
+    def state(self):
+        return self.backend.state()

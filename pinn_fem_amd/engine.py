@@ -32,7 +32,8 @@ class HipEngine:
 
     def __init__(self, model, measured_disp=None, measured_dofs=None, device=None,
                  wg_mode: Optional[int] = None, n_part_blocks: Optional[int] = None,
-                 host_plan: Optional[HostPlan] = None, fe_mode: Optional[int] = None):
+                 host_plan: Optional[HostPlan] = None, fe_mode: Optional[int] = None,
+                 iface=None):
         self.lib = _capi.load()
         self.device = _require_gpu(device)
         self.model = model
@@ -45,6 +46,13 @@ class HipEngine:
         self.adj_ptr, self.adj = t(hp.adj_ptr), t(hp.adj)
         self.f_ext, self.dof_flags, self.meas_val = t(hp.f_ext), t(hp.dof_flags), t(hp.meas_val)
         self.has_measurements = measured_disp is not None and measured_dofs is not None
+        # multi-GPU shard interface: (shared_dofs int32[], shared_slot int32[], n_iface)
+        if iface is not None:
+            self.shared_dofs, self.shared_slot = t(np.asarray(iface[0], dtype=np.int32)), t(np.asarray(iface[1], dtype=np.int32))
+            self.n_shared, self.n_iface = int(len(iface[0])), int(iface[2])
+        else:
+            self.shared_dofs = self.shared_slot = None
+            self.n_shared = self.n_iface = 0
 
         # ---- nets: young, area evaluated; density's parameters only ride along in theta ----------
         mat = model.material
@@ -114,7 +122,7 @@ class HipEngine:
         self.g_ea = torch.zeros(ne, **f32)
         self.grad_u = torch.zeros(nd, **f32)
         self.grad_theta = torch.zeros(max(self.n_theta, 1), **f32)
-        self.partials = torch.zeros(3 * _capi.PF_MAX_BLOCKS + self.n_part_blocks * max(self.pad_total, 1), **f32)
+        self.partials = torch.zeros(3 * _capi.PF_MAX_BLOCKS + (self.n_part_blocks + 16) * max(self.pad_total, 1), **f32)
         self.state_t = torch.zeros(C.sizeof(PfState) // 4, dtype=torch.int32, device=dev)
         self.hist = torch.zeros(1, **f32)
         self.hist_rows = 0
@@ -172,6 +180,9 @@ class HipEngine:
         P.pad_index = self.pad_index.data_ptr()
         P.n_meas_f = float(hp.n_meas)
         P.fe_mode = int(self.fe_mode)
+        P.shared_dofs = self.shared_dofs.data_ptr() if self.n_shared else None
+        P.shared_slot = self.shared_slot.data_ptr() if self.n_shared else None
+        P.n_shared, P.n_iface = self.n_shared, self.n_iface
         self._configured = True
 
     def _ref(self):

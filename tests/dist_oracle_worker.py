@@ -1,0 +1,169 @@
+"""World-size-N CPU worker (gloo) for tests/test_dist_gloo.py.
+
+Drives the PRODUCT's sharding logic (pinn_fem_amd.dist: partition_mesh, shard_host_plan,
+run_iterations and its three collectives) with an oracle-backed ShardBackend standing in for the HIP
+kernels, and writes rank 0's view of the result.  Launched by torch.distributed.run.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+from oracle import pinn_oracle as orc  # noqa: E402
+from pinn_fem_amd import _capi  # noqa: E402
+from pinn_fem_amd.dist import (ShardBackend, make_buffers, partition_mesh, run_iterations,  # noqa: E402
+                               shard_host_plan)
+
+f32 = np.float32
+
+
+class OracleShardBackend(ShardBackend):
+    def __init__(self, pb_global: orc.Problem, cfg: orc.SolverConfig, lam: float, rank: int, world: int):
+        self.device = torch.device("cpu")
+        dim = pb_global.dimension
+        self.shard = sh = partition_mesh(pb_global.elements, pb_global.nnode, dim, rank, world)
+        hp, _ = shard_host_plan(sh, pb_global.nodes, pb_global.loads, pb_global.fixed_dofs,
+                                pb_global.measured_vals, pb_global.measured_dofs, pb_global.ndof)
+        self.hp = hp
+        comp = np.arange(dim)
+        self.dofs_global = (sh.nodes_global[:, None] * dim + comp[None, :]).reshape(-1)
+        copy_net = lambda p: p.copy() if isinstance(p, orc.NetParams) else p
+        self.pb = orc.Problem(nodes=pb_global.nodes[sh.nodes_global], elements=sh.elements_local,
+                              loads=pb_global.loads[self.dofs_global], fixed_dofs=hp.fixed_dofs,
+                              dimension=dim, young=copy_net(pb_global.young),
+                              area=copy_net(pb_global.area), density=copy_net(pb_global.density))
+        self.geo = orc.element_geometry(self.pb)
+        self.cfg, self.lam = cfg, lam
+        self.n_iface = sh.n_iface
+        self.theta = self.pb.theta_list()
+        n_active = sum(t.size for p in (self.pb.young, self.pb.area) if isinstance(p, orc.NetParams)
+                       for t in p.tensors)
+        self.n_theta_active = n_active
+        self.n_active_tensors = sum(len(p.tensors) for p in (self.pb.young, self.pb.area)
+                                    if isinstance(p, orc.NetParams))
+        self.flags = hp.dof_flags
+        self.free = (self.flags & _capi.PF_DOF_FIXED) == 0
+        self.owned = (self.flags & _capi.PF_DOF_GHOST) == 0
+        self.meas = (self.flags & _capi.PF_DOF_MEASURED) != 0
+        self.u = np.zeros(hp.n_dofs, dtype=f32)
+        self.opt_u = orc.AdamState(lr=cfg.learning_rate_u)
+        self.opt_t = orc.AdamState(lr=cfg.learning_rate_theta)
+        self.use_data = pb_global.measured_vals is not None and cfg.alpha_data > 0
+        self.m = float(hp.n_meas)
+        self.history, self.done, self.converged, self.it = [], False, False, 0
+
+    def forward_residual(self):
+        s, *_ = orc.element_stiffness(self.pb, self.geo, self.lam)
+        self.f_part = orc.internal_force(self.geo, s, self.u, self.hp.n_dofs)
+
+    def pack_f(self, iface):
+        iface.zero_()
+        iface[torch.from_numpy(self.shard.shared_slot.astype(np.int64))] = torch.from_numpy(
+            self.f_part[self.shard.shared_dofs])
+
+    def fix_residual(self, iface):
+        f = self.f_part.copy()
+        f[self.shard.shared_dofs] = iface.numpy()[self.shard.shared_slot]
+        r = (f - f32(self.lam) * self.hp.f_ext).astype(f32)
+        r[~self.free] = 0
+        self.g_f = (f32(self.cfg.alpha_physics) * r).astype(f32)
+        self.r2 = float(np.sum((r * r)[self.owned], dtype=f32))
+        d = (self.hp.meas_val - self.u).astype(f32)
+        self.d = d
+        self.d2 = float(np.sum((d * d)[self.meas & self.owned], dtype=f32)) if self.use_data else 0.0
+
+    def backward(self, buf2):
+        gu, gt = orc.vjp_internal_force(self.pb, self.geo, self.u, self.lam, self.g_f)
+        if self.use_data:
+            gd = (f32(self.cfg.alpha_data) / f32(self.m)) * (f32(2.0) * self.d)
+            gu[self.meas] += (-gd[self.meas]).astype(f32)
+        self.grad_u = gu
+        b = buf2.numpy()
+        b[:] = 0
+        b[self.shard.shared_slot] = gu[self.shard.shared_dofs]
+        off = self.n_iface
+        for g in gt:
+            b[off:off + g.size] = g.reshape(-1)
+            off += g.size
+        b[self.n_iface + self.n_theta_active:self.n_iface + self.n_theta_active + 2] = (self.r2, self.d2)
+
+    def update(self, buf2, u2):
+        b = buf2.numpy()
+        self.grad_u[self.shard.shared_dofs] = b[self.shard.shared_slot]
+        self.opt_u.update([self.u], [self.grad_u])
+        grads, off = [], self.n_iface
+        for i, t in enumerate(self.theta):
+            if i < self.n_active_tensors:
+                grads.append(b[off:off + t.size].reshape(t.shape).copy())
+                off += t.size
+            else:
+                grads.append(None)
+        if self.theta:
+            self.opt_t.update(self.theta, grads)
+        self.u[~self.free] = 0
+        u2.numpy()[2] = np.sum((self.u * self.u)[self.free & self.owned], dtype=f32)
+
+    def finalize(self, r2d2, u2):
+        if self.done:
+            return
+        r2, d2 = float(r2d2[0]), float(r2d2[1])
+        lp = f32(0.5) * f32(r2)
+        ld = f32(d2) / f32(self.m) if self.use_data else f32(0)
+        loss = f32(self.cfg.alpha_physics) * lp + (f32(self.cfg.alpha_data) * ld if self.use_data else f32(0))
+        rn = float(np.sqrt(f32(r2)))
+        self.history.append(dict(loss_total=float(loss), loss_physics=float(lp), loss_data=float(ld),
+                                 residual_norm=rn, u_norm=float(np.sqrt(f32(float(u2[0]))))))
+        if self.it > 10 and (rn < self.cfg.tolerance or float(loss) < self.cfg.tolerance):
+            self.done = self.converged = True
+        self.it += 1
+
+
+def build_problem(kind):
+    from helpers import load_npz, mesh_problem
+    if kind == "warren":
+        return mesh_problem(load_npz("step_warren_EA.npz"), (20, 15, None), (2.0, 0.5, 1.0))
+    rec = load_npz("step_chain300_ex4shape.npz")
+    pb = mesh_problem(rec, (20, 15, 10))
+    n = 37                                     # a 37-element prefix of the chain (odd split sizes)
+    fixed = pb.fixed_dofs[pb.fixed_dofs < 2 * (n + 1)]
+    keep = pb.measured_dofs < 2 * (n + 1)
+    loads = np.zeros(2 * (n + 1))
+    loads[2 * n] = 1.0
+    return orc.Problem(nodes=pb.nodes[: n + 1], elements=pb.elements[:n], loads=loads, fixed_dofs=fixed,
+                       dimension=2, young=pb.young, area=pb.area, density=pb.density,
+                       measured_vals=pb.measured_vals[keep], measured_dofs=pb.measured_dofs[keep])
+
+
+def main():
+    kind, n_iter, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    pb = build_problem(kind)
+    cfg = orc.SolverConfig(max_iterations=n_iter, learning_rate_u=0.01, learning_rate_theta=5e-4,
+                           tolerance=1e-12)
+    be = OracleShardBackend(pb, cfg, 0.6, rank, world)
+    run_iterations(be, n_iter, bufs=make_buffers(be))
+    # gather owned displacements on every rank
+    objs = [None] * world
+    dist.all_gather_object(objs, (be.dofs_global[be.owned], be.u[be.owned]))
+    if rank == 0:
+        u = np.zeros(pb.ndof, dtype=f32)
+        for idx, val in objs:
+            u[idx] = val
+        np.savez(out, u=u, theta=np.concatenate([t.reshape(-1) for t in be.theta]) if be.theta else np.zeros(0),
+                 loss=np.array([h["loss_total"] for h in be.history]),
+                 rn=np.array([h["residual_norm"] for h in be.history]),
+                 un=np.array([h["u_norm"] for h in be.history]),
+                 n_iface=be.n_iface)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -305,3 +305,48 @@ def test_unsupported_shapes_fail_loudly():
         model = FEMModel(nodes, np.array([[0, 1]]), mat, np.zeros(4), np.array([0, 1, 3]))
         with pytest.raises(NotImplementedError):
             HipEngine(model)
+
+
+def _run_hip_ranks(kind, world, tmp_path, port):
+    import json
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    out = str(tmp_path / f"hip_{kind}_{world}.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PINNFEM_QUIET="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "dist_hip_worker.py"), kind, out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-5000:]
+    with open(out) as f:
+        return json.load(f)
+
+
+def test_sharded_hip_example_run_two_ranks_one_gpu(tmp_path):
+    """The sharded HIP path (2 ranks sharing this GPU, gloo collectives) reproduces the reference's
+    example4-P run: 3 elements split 2+1, interface node shared."""
+    got = _run_hip_ranks("example4-P", 2, tmp_path, 29631)
+    run = load_run("example4-P")
+    assert got["converged"] == run["result"]["converged"]
+    assert rel_err(got["u"], run["result"]["displacements"]) < 1e-5
+    assert np.max(np.abs(np.array(got["reactions"]) - np.array(run["result"]["reactions"]))) < 1e-5
+    assert abs(got["n_history"] - run["result"]["iterations"]) <= 3
+
+
+def test_sharded_hip_chain_matches_single_engine(tmp_path):
+    """300-element chain, 25 iterations: 3 ranks on one GPU == one engine (sum of shards == whole)."""
+    from pinn_fem_amd.fem.solver import SolverConfig, solve_gd
+    got = _run_hip_ranks("chain300", 3, tmp_path, 29632)
+    rec = load_npz("step_chain300_ex4shape.npz")
+    model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, 10),
+                          (1.0, 1.0, 1.0), theta_from(rec))
+    cfg = SolverConfig(max_iterations=25, learning_rate_u=0.01, learning_rate_theta=5e-4, tolerance=1e-12)
+    ref = solve_gd(model, cfg, rec["meas_vals"], rec["meas_dofs"], target_load_factor=0.7,
+                   u_initial=torch.from_numpy(rec["u"]))
+    assert got["n_history"] == 25
+    assert rel_err(got["u"], ref.displacements.flatten()) < 2e-5
+    assert rel_err(got["loss"], [h["loss_total"] for h in ref.history]) < 1e-4
+    for k, v in ref.nn_parameters.items():
+        assert rel_err(got["theta"][k], v.reshape(-1)) < 2e-5, k
