@@ -40,9 +40,10 @@ extern "C" {
 #define PF_DOF_SHARED 4u   /* dof of a node that also belongs to another rank's shard (multi-GPU) */
 #define PF_DOF_GHOST 8u    /* shared and owned by another rank: excluded from this rank's global sums */
 
-/* weight-gradient reduction engines for pf_net_backward */
-#define PF_WG_SHUFFLE 0 /* wave shuffles, VALU only (slow, simple) */
-#define PF_WG_MFMA 1    /* v_mfma_f32_16x16x4_f32 over LDS-transposed tiles */
+/* MLP engines (pf_problem.wg_mode) */
+#define PF_WG_SHUFFLE 0 /* VALU mat-vecs, weight gradients by wave shuffles (slow cross-check) */
+#define PF_WG_MFMA 1    /* VALU mat-vecs, weight gradients on v_mfma_f32_16x16x4_f32 (LDS tiles) */
+#define PF_WG_MFMA44 2  /* everything on v_mfma_f32_4x4x1_16B_f32, one element per lane (default) */
 
 /* element-force formulations */
 #define PF_FE_REFERENCE 0 /* 4-term dot per row, the reference's order (nn_assembly.py:96-100) */

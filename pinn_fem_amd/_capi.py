@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libpinnfem_hip.so")
 PF_ABI_VERSION = 1
 PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_DOF_FIXED, PF_DOF_MEASURED, PF_DOF_SHARED, PF_DOF_GHOST = 1, 2, 4, 8
-PF_WG_SHUFFLE, PF_WG_MFMA = 0, 1
+PF_WG_SHUFFLE, PF_WG_MFMA, PF_WG_MFMA44 = 0, 1, 2
 PF_FE_REFERENCE, PF_FE_DELTA = 0, 1
 PF_HIST_COLS = 6
 PF_MAX_BLOCKS = 1024

@@ -77,32 +77,27 @@ static int check_problem(const pf_problem* p) {
   return PF_OK;
 }
 
-static int net_forward(const pf_problem* p, int which, hipStream_t s) {
-  switch (padded_width(p->net[which].width)) {
-    case 4: return pf_launch_net_forward_4(p, which, s);
-    case 8: return pf_launch_net_forward_8(p, which, s);
-    case 12: return pf_launch_net_forward_12(p, which, s);
-    case 16: return pf_launch_net_forward_16(p, which, s);
-    case 20: return pf_launch_net_forward_20(p, which, s);
-    case 24: return pf_launch_net_forward_24(p, which, s);
-    case 28: return pf_launch_net_forward_28(p, which, s);
-    case 32: return pf_launch_net_forward_32(p, which, s);
-  }
+#define PF_WIDTH_SWITCH(PREFIX)                                   \
+  switch (padded_width(p->net[which].width)) {                    \
+    case 4: return PREFIX##4(p, which, s);                        \
+    case 8: return PREFIX##8(p, which, s);                        \
+    case 12: return PREFIX##12(p, which, s);                      \
+    case 16: return PREFIX##16(p, which, s);                      \
+    case 20: return PREFIX##20(p, which, s);                      \
+    case 24: return PREFIX##24(p, which, s);                      \
+    case 28: return PREFIX##28(p, which, s);                      \
+    case 32: return PREFIX##32(p, which, s);                      \
+  }                                                               \
   return fail(PF_ERR_UNSUPPORTED, "net width outside 1..32");
+
+static int net_forward(const pf_problem* p, int which, hipStream_t s) {
+  if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_forward_) }
+  PF_WIDTH_SWITCH(pf_launch_net_forward_)
 }
 
 static int net_backward(const pf_problem* p, int which, hipStream_t s) {
-  switch (padded_width(p->net[which].width)) {
-    case 4: return pf_launch_net_backward_4(p, which, s);
-    case 8: return pf_launch_net_backward_8(p, which, s);
-    case 12: return pf_launch_net_backward_12(p, which, s);
-    case 16: return pf_launch_net_backward_16(p, which, s);
-    case 20: return pf_launch_net_backward_20(p, which, s);
-    case 24: return pf_launch_net_backward_24(p, which, s);
-    case 28: return pf_launch_net_backward_28(p, which, s);
-    case 32: return pf_launch_net_backward_32(p, which, s);
-  }
-  return fail(PF_ERR_UNSUPPORTED, "net width outside 1..32");
+  if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_backward_) }
+  PF_WIDTH_SWITCH(pf_launch_net_backward_)
 }
 
 #define PF_TRY(expr, what)                       \

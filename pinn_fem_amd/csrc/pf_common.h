@@ -70,6 +70,18 @@ __device__ __forceinline__ double pf_block_sum_d(double v, double* smem) {
   return t;
 }
 
+// tanh(x) = 1 - 2/(exp(2x)+1): v_mul, v_exp, v_add, v_rcp, v_fma; |abs err| <~ 2e-7 (parity tests
+// run with it).  -DPF_ACCURATE_TANH switches back to the libm-grade tanhf (~25 instructions).
+__device__ __forceinline__ float pf_tanh(float x) {
+#ifdef PF_ACCURATE_TANH
+  return tanhf(x);
+#else
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
+  return fmaf(-2.0f, r, 1.0f);
+#endif
+}
+
 // torch.nn.functional.softplus (beta=1, threshold=20) and its backward factor
 __device__ __forceinline__ float pf_softplus(float z) {
   return z > 20.f ? z : log1pf(expf(z));
@@ -98,7 +110,9 @@ __host__ __device__ inline int pf_node_blocks(int n_nodes, int n_part_blocks) {
 // launchers implemented once per padded width in pf_net.hip (compiled with -DPF_HP=<hp>)
 #define PF_DECL_NET_LAUNCHERS(HP)                                                         \
   int pf_launch_net_forward_##HP(const pf_problem* p, int which, hipStream_t s);          \
-  int pf_launch_net_backward_##HP(const pf_problem* p, int which, hipStream_t s);
+  int pf_launch_net_backward_##HP(const pf_problem* p, int which, hipStream_t s);          \
+  int pf_launch_net44_forward_##HP(const pf_problem* p, int which, hipStream_t s);        \
+  int pf_launch_net44_backward_##HP(const pf_problem* p, int which, hipStream_t s);
 PF_DECL_NET_LAUNCHERS(4)
 PF_DECL_NET_LAUNCHERS(8)
 PF_DECL_NET_LAUNCHERS(12)

@@ -45,7 +45,7 @@ struct Mlp {
       float acc = w[j * 4 + IN];
 #pragma unroll
       for (int c = 0; c < IN; ++c) acc = fmaf(w[j * 4 + c], x[c], acc);
-      h[0][j] = tanhf(acc);
+      h[0][j] = pf_tanh(acc);
     }
 #pragma unroll
     for (int l = 2; l <= L; ++l) {
@@ -55,7 +55,7 @@ struct Mlp {
         float acc = wl[j * (HP + 4) + HP];
 #pragma unroll
         for (int k = 0; k < HP; ++k) acc = fmaf(wl[j * (HP + 4) + k], h[l - 2][k], acc);
-        h[l - 1][j] = tanhf(acc);
+        h[l - 1][j] = pf_tanh(acc);
       }
     }
     const float* __restrict__ wo = w + pf_pad_wo(HP, L);

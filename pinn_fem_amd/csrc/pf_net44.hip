@@ -1,0 +1,411 @@
+// pf_net44.hip — MLP property kernels on the f32 matrix cores, 4x4x1 multi-block form
+// (compile with -DPF_HP=<4..32 step 4>).  Same contract as pf_net.hip (which stays as the VALU
+// cross-check engine): per-element NNProperty.value (FEM/python/fem/properties.py:97-161,
+// examples/json/generic.py:118-142) and its autograd backward incl. the sum over elements of the
+// parameter gradients (loss.backward(), fem/solver.py:289).
+//
+// Why this shape.  v_mfma_f32_4x4x1_16B_f32 computes, for each of 16 blocks of 4 lanes,
+// D[i][j] += A[i]*B[j] with A taken from lane 4*blk+i, B from lane 4*blk+j and D[i][j] in
+// register i of lane 4*blk+j (measured: tools/mfma_probe.hip).  With cbsz=4 every block takes A
+// from block `abid`.  So with ONE ELEMENT PER LANE:
+//   z[4jb+i] += W[4jb+i][k] * h[k]   is   acc_jb = mfma(A = 4 weights (broadcast), B = h[k] (own
+//   register), acc_jb)
+// i.e. a mat-vec per element with the activations never leaving their lane, no LDS, no padding of
+// the 20-wide layers to 32 (the 16x16/32x32 forms would waste 37-61 %), and 16 different 4-weight
+// vectors packed per VGPR (selected by abid), so a whole net's weights sit in <= 16 VGPRs.
+// The parameter gradients  G_l = sum_e dz_l[e] (x) a_{l-1}[e]  use the same instruction without
+// broadcast: each block takes one 4x4 tile of (dz (x) a) of ONE element per instruction, operands
+// fetched from that element's row in LDS; the 41 tiles of a 20-20 net are covered by 3 MFMAs per
+// element and accumulate in 12 registers over the whole grid-stride loop (fixed order, no atomics).
+#include <type_traits>
+#include <stdlib.h>
+#include "pf_common.h"
+
+#ifndef PF_HP
+#error "compile with -DPF_HP=<padded width>"
+#endif
+
+#define PF_CAT2(a, b) a##b
+#define PF_CAT(a, b) PF_CAT2(a, b)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int HP = PF_HP;
+constexpr int NB = HP / 4;  // blocks of 4 hidden units
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+// ---- enumeration of the 4-weight A vectors -------------------------------------------------------
+template <int L>
+struct WIdx {
+  static constexpr int F1 = 0;                                   // (jb, c)      c in [0,4)
+  static constexpr int FH = NB * 4;                              // (l, jb, k)   k in [0,HP], k==HP bias
+  static constexpr int FO = FH + (L - 1) * NB * (HP + 1);        // (k)          row 0 only
+  static constexpr int FWD_END = FO + HP + 1;
+  static constexpr int BO = FWD_END;                             // (kb)
+  static constexpr int BH = BO + NB;                             // (l, kb, j)   transposed blocks
+  static constexpr int END = BH + (L - 1) * NB * HP;
+  static constexpr int NV_FWD = (FWD_END + 15) / 16;
+  static constexpr int NV_ALL = (END + 15) / 16;
+  static constexpr int f1(int jb, int c) { return F1 + jb * 4 + c; }
+  static constexpr int fh(int l, int jb, int k) { return FH + ((l - 2) * NB + jb) * (HP + 1) + k; }
+  static constexpr int fo(int k) { return FO + k; }
+  static constexpr int bo(int kb) { return BO + kb; }
+  static constexpr int bh(int l, int kb, int j) { return BH + ((l - 2) * NB + kb) * HP + j; }
+
+  // offset in the padded parameter image of component r of vector t, or -1 for a structural zero
+  __device__ static int src(int t, int r) {
+    if (t < FH) return (4 * (t / 4) + r) * 4 + (t % 4);
+    if (t < FO) {
+      const int q = t - FH, l2 = q / (NB * (HP + 1)), rem = q % (NB * (HP + 1));
+      const int jb = rem / (HP + 1), k = rem % (HP + 1);
+      return pf_pad_wh(HP, l2 + 2) + (4 * jb + r) * (HP + 4) + k;
+    }
+    if (t < FWD_END) return r == 0 ? pf_pad_wo(HP, L) + (t - FO) : -1;
+    if (t < BH) return pf_pad_wo(HP, L) + 4 * (t - BO) + r;
+    if (t < END) {
+      const int q = t - BH, l2 = q / (NB * HP), rem = q % (NB * HP);
+      const int kb = rem / HP, j = rem % HP;
+      return pf_pad_wh(HP, l2 + 2) + j * (HP + 4) + 4 * kb + r;
+    }
+    return -1;
+  }
+};
+
+template <int NV, int L>
+__device__ __forceinline__ void load_weights(float (&wv)[NV], const float* __restrict__ w, int lane) {
+  sfor<0, NV>([&](auto v) {
+    constexpr int V = v;
+    const int off = WIdx<L>::src(16 * V + (lane >> 2), lane & 3);
+    wv[V] = off >= 0 ? w[off] : 0.f;
+  });
+}
+
+#define MFMA44(T, b, acc) __builtin_amdgcn_mfma_f32_4x4x1f32(wv[(T) / 16], (b), (acc), 4, (T) % 16, 0)
+
+template <int IN>
+__device__ __forceinline__ void load_input44(float (&x)[4], const float* __restrict__ ecent, int e,
+                                             float lam, bool live) {
+  x[0] = x[1] = x[2] = x[3] = 0.f;
+  if (!live) return;
+  x[0] = lam;
+  if (IN == 3) {
+    const float2 c = reinterpret_cast<const float2*>(ecent)[e];
+    x[1] = c.x;
+    x[2] = c.y;
+    x[3] = 1.f;
+  } else {
+    x[1] = ecent[e];
+    x[2] = 1.f;
+  }
+}
+
+// forward through the net; h[l][k] tanh activations, returns pre-softplus output z
+template <int L, int IN, int NV>
+__device__ __forceinline__ float mlp_forward44(const float (&wv)[NV], const float (&x)[4],
+                                               float (&h)[L][HP]) {
+  using W = WIdx<L>;
+  sfor<0, NB>([&](auto jb) {
+    constexpr int JB = jb;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = MFMA44(W::f1(JB, IN), 1.0f, acc);  // bias first, like addmm(bias, x, W^T)
+    sfor<0, IN>([&](auto c) { constexpr int C = c; acc = MFMA44(W::f1(JB, C), x[C], acc); });
+    sfor<0, 4>([&](auto r) { constexpr int R = r; h[0][4 * JB + R] = pf_tanh(acc[R]); });
+  });
+  sfor<2, L + 1>([&](auto l) {
+    constexpr int LL = l;
+    // k outer / jb inner: NB independent accumulators between two updates of the same one
+    f32x4 acc[NB];
+    sfor<0, NB>([&](auto jb) {
+      constexpr int JB = jb;
+      acc[JB] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[JB] = MFMA44(W::fh(LL, JB, HP), 1.0f, acc[JB]);
+    });
+    sfor<0, HP>([&](auto k) {
+      constexpr int K = k;
+      sfor<0, NB>([&](auto jb) { constexpr int JB = jb; acc[JB] = MFMA44(W::fh(LL, JB, K), h[LL - 2][K], acc[JB]); });
+    });
+    sfor<0, NB>([&](auto jb) {
+      constexpr int JB = jb;
+      sfor<0, 4>([&](auto r) { constexpr int R = r; h[LL - 1][4 * JB + R] = pf_tanh(acc[JB][R]); });
+    });
+  });
+  // output unit: 4 partial chains to keep the MFMA pipe busy, summed at the end
+  f32x4 ao[4];
+  sfor<0, 4>([&](auto q) { constexpr int Q = q; ao[Q] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+  ao[0] = MFMA44(W::fo(HP), 1.0f, ao[0]);
+  sfor<0, HP>([&](auto k) { constexpr int K = k; ao[(K + 1) % 4] = MFMA44(W::fo(K), h[L - 1][K], ao[(K + 1) % 4]); });
+  return (ao[0][0] + ao[1][0]) + (ao[2][0] + ao[3][0]);
+}
+
+// ---- forward kernel --------------------------------------------------------------------------------
+template <int L, int IN>
+__global__ __launch_bounds__(256) void k_net44_forward(pf_problem P, int which) {
+  if (P.state->done) return;
+  const pf_net net = P.net[which];
+  const float* __restrict__ w = P.theta_pad + net.pad_off;
+  float* __restrict__ out = which == 0 ? P.prop_e : P.prop_a;
+  constexpr int NV = WIdx<L>::NV_FWD;
+  float wv[NV];
+  load_weights<NV, L>(wv, w, threadIdx.x & 63);
+  const int n = P.mesh.n_elems;
+  // block-uniform trip count: every lane of a wave executes the same MFMAs (EXEC all ones)
+  for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
+    const int e = base + threadIdx.x;
+    const bool live = e < n;
+    float x[4], h[L][HP];
+    load_input44<IN>(x, P.mesh.ecent, e, P.lam, live);
+    const float z = mlp_forward44<L, IN, NV>(wv, x, h);
+    if (live) out[e] = (net.positive ? pf_softplus(z) : z) * net.scale;
+  }
+}
+
+// ---- LDS row of one element for the parameter-gradient tiles ------------------------------------------
+template <int L>
+struct Row {
+  static constexpr int DZ0 = 0;                       // dz_l at (l-1)*HP, l = 1..L
+  static constexpr int DZO = L * HP;                  // [g_z, 0, 0, 0]
+  static constexpr int XE = L * HP + 4;               // x ext (4)
+  static constexpr int HE = L * HP + 8;               // h_l ext at HE + (l-1)*(HP+4): h, 1, 0, 0, 0
+  static constexpr int LEN = HE + L * (HP + 4);
+  // stride = 4 (mod 32) floats: b128 writes of 8 consecutive lanes hit 32 distinct banks
+  static constexpr int STRIDE = LEN + ((4 - LEN % 32) + 32) % 32;
+  static constexpr int NT_L1 = NB;
+  static constexpr int NT_H = (L - 1) * NB * (NB + 1);
+  static constexpr int NT_O = NB + 1;
+  static constexpr int NTILE = NT_L1 + NT_H + NT_O;
+  static constexpr int M = (NTILE + 15) / 16;         // MFMAs per element
+
+  // tile tau -> LDS columns of its A (dz) and B (activation) 4-vectors and its place in the padded
+  // gradient image: entry (r, jq) of the tile goes to goff + r*gstride + jq  (r < rmax)
+  __device__ static void decode(int tau, int& colA, int& colB, int& goff, int& gstride, int& rmax) {
+    if (tau < NT_L1) {
+      colA = 4 * tau; colB = XE; goff = (4 * tau) * 4; gstride = 4; rmax = 4;
+    } else if (tau < NT_L1 + NT_H) {
+      const int q = tau - NT_L1, l2 = q / (NB * (NB + 1)), rem = q % (NB * (NB + 1));
+      const int a = rem / (NB + 1), c = rem % (NB + 1);
+      colA = (l2 + 1) * HP + 4 * a;
+      colB = HE + l2 * (HP + 4) + 4 * c;
+      goff = pf_pad_wh(HP, l2 + 2) + (4 * a) * (HP + 4) + 4 * c; gstride = HP + 4; rmax = 4;
+    } else {
+      const int c = tau - NT_L1 - NT_H;
+      colA = DZO; colB = HE + (L - 1) * (HP + 4) + 4 * c;
+      goff = pf_pad_wo(HP, L) + 4 * c; gstride = 0; rmax = 1;
+    }
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void row_write(float* row, int off, const float (&v)[N]) {
+  static_assert(N % 4 == 0, "");
+  sfor<0, N / 4>([&](auto q) {
+    constexpr int Q = q;
+    *reinterpret_cast<float4*>(row + off + 4 * Q) = make_float4(v[4 * Q], v[4 * Q + 1], v[4 * Q + 2], v[4 * Q + 3]);
+  });
+}
+
+// ---- backward kernel -------------------------------------------------------------------------------------
+constexpr int BW_THREADS = PF_NET_THREADS;
+constexpr int BW_WAVES = BW_THREADS / 64;
+
+template <int L, int IN>
+__global__ __launch_bounds__(BW_THREADS) void k_net44_backward(pf_problem P, int which) {
+  if (P.state->done) return;
+  extern __shared__ __align__(16) float lds[];
+  using W = WIdx<L>;
+  using R = Row<L>;
+  constexpr int NV = W::NV_ALL;
+  constexpr int PADC = pf_pad_count(HP, L);
+  constexpr int M = R::M;
+  const pf_net net = P.net[which];
+  const pf_net onet = P.net[1 - which];
+  const float* __restrict__ w = P.theta_pad + net.pad_off;
+  const float* __restrict__ other = which == 0 ? P.prop_a : P.prop_e;
+  const float* __restrict__ g_ea = P.g_ea;
+  const int n = P.mesh.n_elems;
+  const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
+
+  float wv[NV];
+  load_weights<NV, L>(wv, w, lane);
+
+  float* rows = lds + wvid * 64 * R::STRIDE;       // this wave's 64 element rows
+  float* myrow = rows + lane * R::STRIDE;
+  // per-lane operand columns of the M gradient tiles this lane's block serves
+  const float* pa[M];
+  const float* pb[M];
+  sfor<0, M>([&](auto m) {
+    constexpr int MM = m;
+    int tau = 16 * MM + (lane >> 2);
+    if (tau >= R::NTILE) tau = R::NTILE - 1;   // duplicate of the last tile, never written out
+    int colA, colB, goff, gstride, rmax;
+    R::decode(tau, colA, colB, goff, gstride, rmax);
+    pa[MM] = rows + colA + (lane & 3);
+    pb[MM] = rows + colB + (lane & 3);
+  });
+  f32x4 accw[M];
+  sfor<0, M>([&](auto m) { constexpr int MM = m; accw[MM] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+
+  // constant parts of the row: the zero paddings and the ones of the ext vectors
+  {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < R::STRIDE; c += 4) *reinterpret_cast<float4*>(myrow + c) = z4;
+  }
+
+  for (int base = blockIdx.x * BW_THREADS; base < n; base += gridDim.x * BW_THREADS) {
+    const int e = base + threadIdx.x;
+    const bool live = e < n;
+    float x[4], h[L][HP];
+    load_input44<IN>(x, P.mesh.ecent, e, P.lam, live);
+    const float z = mlp_forward44<L, IN, NV>(wv, x, h);
+    float gz = 0.f;
+    if (live) {
+      const float oth = onet.enabled ? other[e] : onet.scale;
+      float g = g_ea[e] * oth;   // mul backward of young*area        (nn_assembly.py:74)
+      g = g * net.scale;         // output*scale backward              (properties.py:156)
+      gz = net.positive ? g * pf_softplus_grad(z) : g;
+    }
+
+    // ---- row: activations ---------------------------------------------------------------------------
+    *reinterpret_cast<float4*>(myrow + R::XE) = make_float4(x[0], x[1], x[2], x[3]);
+    *reinterpret_cast<float4*>(myrow + R::DZO) = make_float4(gz, 0.f, 0.f, 0.f);
+    sfor<1, L + 1>([&](auto l) {
+      constexpr int LL = l;
+      row_write<HP>(myrow, R::HE + (LL - 1) * (HP + 4), h[LL - 1]);
+      *reinterpret_cast<float4*>(myrow + R::HE + (LL - 1) * (HP + 4) + HP) = make_float4(1.f, 0.f, 0.f, 0.f);
+    });
+
+    // ---- back-propagation, natural layout ---------------------------------------------------------------
+    float dz[HP];
+    sfor<0, NB>([&](auto kb) {
+      constexpr int KB = kb;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = MFMA44(W::bo(KB), gz, acc);                      // dh_L = Wo^T g_z
+      sfor<0, 4>([&](auto r) {
+        constexpr int RR = r;
+        const float hk = h[L - 1][4 * KB + RR];
+        dz[4 * KB + RR] = acc[RR] * fmaf(-hk, hk, 1.f);      // tanh backward
+      });
+    });
+    row_write<HP>(myrow, (L - 1) * HP, dz);
+    sfor<0, L - 1>([&](auto s) {
+      constexpr int LL = L - s;                               // L .. 2
+      f32x4 acc[NB];
+      sfor<0, NB>([&](auto kb) { constexpr int KB = kb; acc[KB] = f32x4{0.f, 0.f, 0.f, 0.f}; });
+      sfor<0, HP>([&](auto j) {
+        constexpr int J = j;
+        sfor<0, NB>([&](auto kb) { constexpr int KB = kb; acc[KB] = MFMA44(W::bh(LL, KB, J), dz[J], acc[KB]); });
+      });
+      sfor<0, NB>([&](auto kb) {
+        constexpr int KB = kb;
+        sfor<0, 4>([&](auto r) {
+          constexpr int RR = r;
+          const float hk = h[LL - 2][4 * KB + RR];
+          dz[4 * KB + RR] = acc[KB][RR] * fmaf(-hk, hk, 1.f);
+        });
+      });
+      row_write<HP>(myrow, (LL - 2) * HP, dz);
+    });
+
+    // ---- parameter-gradient tiles: one element per step, all 64 lanes cooperate -------------------------------
+    // rows are private to the wave and LDS executes a wave's accesses in order: only the compiler
+    // has to be told not to move the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 8
+    for (int q = 0; q < 64; ++q) {
+      sfor<0, M>([&](auto m) {
+        constexpr int MM = m;
+        accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[MM][q * R::STRIDE], pb[MM][q * R::STRIDE],
+                                                      accw[MM], 0, 0, 0);
+      });
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  // ---- write-out: tiles -> per-wave padded image in LDS -> fixed-order sum over waves -> partial row -----------
+  __syncthreads();
+  for (int i = threadIdx.x; i < BW_WAVES * PADC; i += BW_THREADS) lds[i] = 0.f;
+  __syncthreads();
+  float* wimg = lds + wvid * PADC;
+  sfor<0, M>([&](auto m) {
+    constexpr int MM = m;
+    const int tau = 16 * MM + (lane >> 2);
+    if (tau < R::NTILE) {
+      int colA, colB, goff, gstride, rmax;
+      R::decode(tau, colA, colB, goff, gstride, rmax);
+      sfor<0, 4>([&](auto r) {
+        constexpr int RR = r;
+        if (RR < rmax) wimg[goff + RR * gstride + (lane & 3)] = accw[MM][RR];
+      });
+    }
+  });
+  __syncthreads();
+  float* __restrict__ prow = P.partials + PF_PART_WG + (size_t)blockIdx.x * P.pad_total + net.pad_off;
+  for (int i = threadIdx.x; i < PADC; i += BW_THREADS) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < BW_WAVES; ++q) t += lds[q * PADC + i];
+    prow[i] = t;
+  }
+}
+
+template <int L, int IN>
+int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
+  const int n = p->mesh.n_elems;
+  int nb = (n + 255) / 256;
+  // EXPERIMENT knobs: PF_FWD_BLOCKS caps the grid, PF_FWD_LDS (bytes of dummy dynamic LDS) limits
+  // the blocks resident per CU
+  static const int cap = getenv("PF_FWD_BLOCKS") ? atoi(getenv("PF_FWD_BLOCKS")) : 2048;
+  static const int ldsb = getenv("PF_FWD_LDS") ? atoi(getenv("PF_FWD_LDS")) : 0;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL((k_net44_forward<L, IN>), dim3(nb), dim3(256), ldsb, s, *p, which);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
+template <int L, int IN>
+int launch_bwd(const pf_problem* p, int which, hipStream_t s) {
+  const int nb = pf_net_blocks(p->mesh.n_elems, p->n_part_blocks);
+  constexpr int PADC = pf_pad_count(HP, L);
+  constexpr int row_floats = BW_WAVES * 64 * Row<L>::STRIDE;
+  constexpr int lds_floats = row_floats > BW_WAVES * PADC ? row_floats : BW_WAVES * PADC;
+  static_assert(lds_floats * 4 <= 160 * 1024, "LDS budget");
+  hipLaunchKernelGGL((k_net44_backward<L, IN>), dim3(nb), dim3(BW_THREADS), lds_floats * sizeof(float), s,
+                     *p, which);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+
+}  // namespace
+
+#define PF_DISPATCH(FN)                                             \
+  const pf_net& net = p->net[which];                                \
+  const int L = net.n_hidden, IN = net.in_dim;                      \
+  if (IN == 3) {                                                    \
+    if (L == 1) return FN<1, 3>(p, which, s);                       \
+    if (L == 2) return FN<2, 3>(p, which, s);                       \
+    if (L == 3) return FN<3, 3>(p, which, s);                       \
+  } else if (IN == 2) {                                             \
+    if (L == 1) return FN<1, 2>(p, which, s);                       \
+    if (L == 2) return FN<2, 2>(p, which, s);                       \
+    if (L == 3) return FN<3, 2>(p, which, s);                       \
+  }                                                                 \
+  pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)"); \
+  return PF_ERR_UNSUPPORTED;
+
+int PF_CAT(pf_launch_net44_forward_, PF_HP)(const pf_problem* p, int which, hipStream_t s) {
+  PF_DISPATCH(launch_fwd)
+}
+int PF_CAT(pf_launch_net44_backward_, PF_HP)(const pf_problem* p, int which, hipStream_t s) {
+  PF_DISPATCH(launch_bwd)
+}

@@ -99,7 +99,7 @@ class HipEngine:
         self.pad_index = torch.tensor(pad_index if pad_index else [0], dtype=torch.int32, device=dev)
 
         if wg_mode is None:
-            wg_mode = int(os.environ.get("PINNFEM_WG_MODE", _capi.PF_WG_MFMA))
+            wg_mode = int(os.environ.get("PINNFEM_WG_MODE", _capi.PF_WG_MFMA44))
         self.wg_mode = wg_mode
         if fe_mode is None:
             fe_mode = int(os.environ.get("PINNFEM_FE_MODE", _capi.PF_FE_REFERENCE))

@@ -12,7 +12,7 @@ from helpers import (example_problem, load_npz, load_run, mesh_problem, orc, pro
 
 pytestmark = pytest.mark.gpu
 
-WG_MODES = [1, 0]  # PF_WG_MFMA, PF_WG_SHUFFLE
+WG_MODES = [2, 1, 0]  # PF_WG_MFMA44 (default), PF_WG_MFMA, PF_WG_SHUFFLE
 
 
 def _engine(model, mv, md, wg, fe=0):
