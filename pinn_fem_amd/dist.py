@@ -15,7 +15,7 @@ For a 1-D chain cut into G shards the interface has 2(G-1) dofs, so the traffic 
 iteration regardless of N — latency-bound, as SURVEY.md §5/§8(e) predicts.
 
 The iteration driver (`run_iterations`) only talks to a ShardBackend; the product backend is
-HipShardBackend (HIP kernels).  Tests drive the same driver with an oracle-backed backend over gloo.
+HipShardBackend (HIP kernels).  Tests drive the same driver with a CPU reference backend over gloo.
 """
 from __future__ import annotations
 
