@@ -26,7 +26,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.j
 
 def _sources():
     units = [("pf_api.o", "pf_api.hip", []), ("pf_mesh.o", "pf_mesh.hip", [])]
-    units += [(f"pf_net44_{w}.o", "pf_net44.hip", [f"-DPF_HP={w}"]) for w in reversed(WIDTHS)]
+    # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
+    # removes the v_accvgpr_read copies in front of every tanh
+    units += [(f"pf_net44_{w}.o", "pf_net44.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
+              for w in reversed(WIDTHS)]
     units += [(f"pf_net_{w}.o", "pf_net.hip", [f"-DPF_HP={w}"]) for w in WIDTHS]
     return units
 

@@ -82,14 +82,22 @@ __device__ __forceinline__ float pf_tanh(float x) {
 #endif
 }
 
-// torch.nn.functional.softplus (beta=1, threshold=20) and its backward factor
+// torch.nn.functional.softplus (beta=1, threshold=20) and its backward factor.
+// softplus(z) = max(z,0) + log1p(exp(-|z|)); log1p(e) by Kahan's correction log(u)*e/(u-1), u = 1+e,
+// which keeps full relative accuracy for tiny e without libm's ~100-instruction log1pf.
 __device__ __forceinline__ float pf_softplus(float z) {
-  return z > 20.f ? z : log1pf(expf(z));
+  if (z > 20.f) return z;
+  const float e = expf(-fabsf(z));
+  const float u = 1.f + e;
+  const float d = u - 1.f;                       // exact
+  const float l = d == 0.f ? e : __logf(u) * (e * __builtin_amdgcn_rcpf(d));
+  return fmaxf(z, 0.f) + l;
 }
+// torch softplus_backward: z > 20 ? 1 : e^z/(e^z+1)
 __device__ __forceinline__ float pf_softplus_grad(float z) {
   if (z > 20.f) return 1.f;
   const float ez = expf(z);
-  return ez / (ez + 1.f);
+  return ez * __builtin_amdgcn_rcpf(ez + 1.f);
 }
 
 // blocks the element-parallel net kernels launch for n elements

@@ -113,13 +113,29 @@ template <int L, int IN, int NV>
 __device__ __forceinline__ float mlp_forward44(const float (&wv)[NV], const float (&x)[4],
                                                float (&h)[L][HP]) {
   using W = WIdx<L>;
-  sfor<0, NB>([&](auto jb) {
-    constexpr int JB = jb;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = MFMA44(W::f1(JB, IN), 1.0f, acc);  // bias first, like addmm(bias, x, W^T)
-    sfor<0, IN>([&](auto c) { constexpr int C = c; acc = MFMA44(W::f1(JB, C), x[C], acc); });
-    sfor<0, 4>([&](auto r) { constexpr int R = r; h[0][4 * JB + R] = pf_tanh(acc[R]); });
-  });
+  // PHASES.  On gfx950 an f32 MFMA and f32 VALU share one pipe and every MFMA<->VALU switch in the
+  // issue stream costs tens of cycles (tools/mfma_rate.hip); left alone, the scheduler interleaves
+  // the tanh of layer l one-by-one with the MFMAs of layer l+1 (222 switches per 64 elements).
+  // sched_barrier(0) pins each layer to [all MFMAs][all tanh].
+#define PF_PHASE() __builtin_amdgcn_sched_barrier(0)
+  {
+    f32x4 acc[NB];
+    sfor<0, NB>([&](auto jb) {
+      constexpr int JB = jb;
+      acc[JB] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[JB] = MFMA44(W::f1(JB, IN), 1.0f, acc[JB]);  // bias first, like addmm(bias, x, W^T)
+    });
+    sfor<0, IN>([&](auto c) {
+      constexpr int C = c;
+      sfor<0, NB>([&](auto jb) { constexpr int JB = jb; acc[JB] = MFMA44(W::f1(JB, C), x[C], acc[JB]); });
+    });
+    PF_PHASE();
+    sfor<0, NB>([&](auto jb) {
+      constexpr int JB = jb;
+      sfor<0, 4>([&](auto r) { constexpr int R = r; h[0][4 * JB + R] = pf_tanh(acc[JB][R]); });
+    });
+    PF_PHASE();
+  }
   sfor<2, L + 1>([&](auto l) {
     constexpr int LL = l;
     // k outer / jb inner: NB independent accumulators between two updates of the same one
@@ -133,16 +149,19 @@ __device__ __forceinline__ float mlp_forward44(const float (&wv)[NV], const floa
       constexpr int K = k;
       sfor<0, NB>([&](auto jb) { constexpr int JB = jb; acc[JB] = MFMA44(W::fh(LL, JB, K), h[LL - 2][K], acc[JB]); });
     });
+    PF_PHASE();
     sfor<0, NB>([&](auto jb) {
       constexpr int JB = jb;
       sfor<0, 4>([&](auto r) { constexpr int R = r; h[LL - 1][4 * JB + R] = pf_tanh(acc[JB][R]); });
     });
+    PF_PHASE();
   });
   // output unit: 4 partial chains to keep the MFMA pipe busy, summed at the end
   f32x4 ao[4];
   sfor<0, 4>([&](auto q) { constexpr int Q = q; ao[Q] = f32x4{0.f, 0.f, 0.f, 0.f}; });
   ao[0] = MFMA44(W::fo(HP), 1.0f, ao[0]);
   sfor<0, HP>([&](auto k) { constexpr int K = k; ao[(K + 1) % 4] = MFMA44(W::fo(K), h[L - 1][K], ao[(K + 1) % 4]); });
+  PF_PHASE();
   return (ao[0][0] + ao[1][0]) + (ao[2][0] + ao[3][0]);
 }
 
@@ -176,8 +195,10 @@ struct Row {
   static constexpr int XE = L * HP + 4;               // x ext (4)
   static constexpr int HE = L * HP + 8;               // h_l ext at HE + (l-1)*(HP+4): h, 1, 0, 0, 0
   static constexpr int LEN = HE + L * (HP + 4);
-  // stride = 4 (mod 32) floats: b128 writes of 8 consecutive lanes hit 32 distinct banks
-  static constexpr int STRIDE = LEN + ((4 - LEN % 32) + 32) % 32;
+  // LDS image of one pass (32 elements) is COLUMN-major: column c of element q at c*CS + q, so the 4x4
+  // tile operands of 4 consecutive elements come back from ONE ds_read_b128 with an immediate offset
+  // (no address arithmetic between the MFMAs).  CS = 36 = 4 (mod 32) spreads the columns over banks.
+  static constexpr int CS = 36;
   static constexpr int NT_L1 = NB;
   static constexpr int NT_H = (L - 1) * NB * (NB + 1);
   static constexpr int NT_O = NB + 1;
@@ -203,21 +224,12 @@ struct Row {
   }
 };
 
-template <int N>
-__device__ __forceinline__ void row_write(float* row, int off, const float (&v)[N]) {
-  static_assert(N % 4 == 0, "");
-  sfor<0, N / 4>([&](auto q) {
-    constexpr int Q = q;
-    *reinterpret_cast<float4*>(row + off + 4 * Q) = make_float4(v[4 * Q], v[4 * Q + 1], v[4 * Q + 2], v[4 * Q + 3]);
-  });
-}
-
 // ---- backward kernel -------------------------------------------------------------------------------------
 constexpr int BW_THREADS = PF_NET_THREADS;
 constexpr int BW_WAVES = BW_THREADS / 64;
 
 template <int L, int IN>
-__global__ __launch_bounds__(BW_THREADS) void k_net44_backward(pf_problem P, int which) {
+__global__ __launch_bounds__(BW_THREADS, (L <= 2 ? 3 : 2)) void k_net44_backward(pf_problem P, int which) {
   if (P.state->done) return;
   extern __shared__ __align__(16) float lds[];
   using W = WIdx<L>;
@@ -236,8 +248,11 @@ __global__ __launch_bounds__(BW_THREADS) void k_net44_backward(pf_problem P, int
   float wv[NV];
   load_weights<NV, L>(wv, w, lane);
 
-  float* rows = lds + wvid * 64 * R::STRIDE;       // this wave's 64 element rows
-  float* myrow = rows + lane * R::STRIDE;
+  // LDS: one pass = 32 elements, column-major (R::CS floats per column); two passes per 64-element
+  // batch keep the footprint at 13.8 kB per wave for a 20-20 net, so 3 waves per SIMD stay resident
+  constexpr int ROWS = 32;
+  float* cols = lds + wvid * R::LEN * R::CS;
+  float* mycol = cols + (lane & (ROWS - 1));       // + c*CS addresses column c of this lane's element
   // per-lane operand columns of the M gradient tiles this lane's block serves
   const float* pa[M];
   const float* pb[M];
@@ -247,16 +262,19 @@ __global__ __launch_bounds__(BW_THREADS) void k_net44_backward(pf_problem P, int
     if (tau >= R::NTILE) tau = R::NTILE - 1;   // duplicate of the last tile, never written out
     int colA, colB, goff, gstride, rmax;
     R::decode(tau, colA, colB, goff, gstride, rmax);
-    pa[MM] = rows + colA + (lane & 3);
-    pb[MM] = rows + colB + (lane & 3);
+    pa[MM] = cols + (colA + (lane & 3)) * R::CS;
+    pb[MM] = cols + (colB + (lane & 3)) * R::CS;
   });
   f32x4 accw[M];
   sfor<0, M>([&](auto m) { constexpr int MM = m; accw[MM] = f32x4{0.f, 0.f, 0.f, 0.f}; });
 
-  // constant parts of the row: the zero paddings and the ones of the ext vectors
-  {
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < R::STRIDE; c += 4) *reinterpret_cast<float4*>(myrow + c) = z4;
+  // constant columns: zero paddings and the ones of the ext vectors
+  for (int i = lane; i < R::LEN * R::CS; i += 64) cols[i] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < ROWS) {
+    sfor<1, L + 1>([&](auto l) { constexpr int LL = l; mycol[(R::HE + (LL - 1) * (HP + 4) + HP) * R::CS] = 1.f; });
   }
 
   for (int base = blockIdx.x * BW_THREADS; base < n; base += gridDim.x * BW_THREADS) {
@@ -273,64 +291,99 @@ __global__ __launch_bounds__(BW_THREADS) void k_net44_backward(pf_problem P, int
       gz = net.positive ? g * pf_softplus_grad(z) : g;
     }
 
-    // ---- row: activations ---------------------------------------------------------------------------
-    *reinterpret_cast<float4*>(myrow + R::XE) = make_float4(x[0], x[1], x[2], x[3]);
-    *reinterpret_cast<float4*>(myrow + R::DZO) = make_float4(gz, 0.f, 0.f, 0.f);
-    sfor<1, L + 1>([&](auto l) {
-      constexpr int LL = l;
-      row_write<HP>(myrow, R::HE + (LL - 1) * (HP + 4), h[LL - 1]);
-      *reinterpret_cast<float4*>(myrow + R::HE + (LL - 1) * (HP + 4) + HP) = make_float4(1.f, 0.f, 0.f, 0.f);
-    });
-
-    // ---- back-propagation, natural layout ---------------------------------------------------------------
-    float dz[HP];
-    sfor<0, NB>([&](auto kb) {
-      constexpr int KB = kb;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = MFMA44(W::bo(KB), gz, acc);                      // dh_L = Wo^T g_z
-      sfor<0, 4>([&](auto r) {
-        constexpr int RR = r;
-        const float hk = h[L - 1][4 * KB + RR];
-        dz[4 * KB + RR] = acc[RR] * fmaf(-hk, hk, 1.f);      // tanh backward
+    // ---- back-propagation, natural layout: dzs[l-1] = dL/d(pre-activation of layer l) -------------------
+    float dzs[L][HP];
+    PF_PHASE();
+    {
+      f32x4 acc[NB];
+      sfor<0, NB>([&](auto kb) {
+        constexpr int KB = kb;
+        acc[KB] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[KB] = MFMA44(W::bo(KB), gz, acc[KB]);              // dh_L = Wo^T g_z
       });
-    });
-    row_write<HP>(myrow, (L - 1) * HP, dz);
+      PF_PHASE();
+      sfor<0, NB>([&](auto kb) {
+        constexpr int KB = kb;
+        sfor<0, 4>([&](auto r) {
+          constexpr int RR = r;
+          const float hk = h[L - 1][4 * KB + RR];
+          dzs[L - 1][4 * KB + RR] = acc[KB][RR] * fmaf(-hk, hk, 1.f);   // tanh backward
+        });
+      });
+      PF_PHASE();
+    }
     sfor<0, L - 1>([&](auto s) {
       constexpr int LL = L - s;                               // L .. 2
       f32x4 acc[NB];
       sfor<0, NB>([&](auto kb) { constexpr int KB = kb; acc[KB] = f32x4{0.f, 0.f, 0.f, 0.f}; });
       sfor<0, HP>([&](auto j) {
         constexpr int J = j;
-        sfor<0, NB>([&](auto kb) { constexpr int KB = kb; acc[KB] = MFMA44(W::bh(LL, KB, J), dz[J], acc[KB]); });
+        sfor<0, NB>([&](auto kb) { constexpr int KB = kb; acc[KB] = MFMA44(W::bh(LL, KB, J), dzs[LL - 1][J], acc[KB]); });
       });
+      PF_PHASE();
       sfor<0, NB>([&](auto kb) {
         constexpr int KB = kb;
         sfor<0, 4>([&](auto r) {
           constexpr int RR = r;
           const float hk = h[LL - 2][4 * KB + RR];
-          dz[4 * KB + RR] = acc[KB][RR] * fmaf(-hk, hk, 1.f);
+          dzs[LL - 2][4 * KB + RR] = acc[KB][RR] * fmaf(-hk, hk, 1.f);
         });
       });
-      row_write<HP>(myrow, (LL - 2) * HP, dz);
+      PF_PHASE();
     });
 
-    // ---- parameter-gradient tiles: one element per step, all 64 lanes cooperate -------------------------------
-    // rows are private to the wave and LDS executes a wave's accesses in order: only the compiler
-    // has to be told not to move the reads above the writes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 8
-    for (int q = 0; q < 64; ++q) {
-      sfor<0, M>([&](auto m) {
-        constexpr int MM = m;
-        accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[MM][q * R::STRIDE], pb[MM][q * R::STRIDE],
-                                                      accw[MM], 0, 0, 0);
-      });
+    // ---- parameter-gradient tiles: two passes of 32 elements; in each pass every step takes ONE
+    // element's row and all 64 lanes cooperate on its 4x4 tiles ------------------------------------------
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      if ((lane >> 5) == hf) {
+        sfor<0, 4>([&](auto c) { constexpr int C = c; mycol[(R::XE + C) * R::CS] = x[C]; });
+        mycol[R::DZO * R::CS] = gz;
+        sfor<1, L + 1>([&](auto l) {
+          constexpr int LL = l;
+          sfor<0, HP>([&](auto k) {
+            constexpr int K = k;
+            mycol[((LL - 1) * HP + K) * R::CS] = dzs[LL - 1][K];
+            mycol[(R::HE + (LL - 1) * (HP + 4) + K) * R::CS] = h[LL - 1][K];
+          });
+        });
+      }
+      // columns are private to the wave and LDS executes a wave's accesses in order: only the
+      // compiler has to be told not to move the reads above the writes
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      PF_PHASE();
+#pragma unroll 2
+      for (int q4 = 0; q4 < ROWS / 4; ++q4) {
+        float4 av[M], bv[M];
+        sfor<0, M>([&](auto m) {
+          constexpr int MM = m;
+          av[MM] = *reinterpret_cast<const float4*>(pa[MM] + 4 * q4);
+          bv[MM] = *reinterpret_cast<const float4*>(pb[MM] + 4 * q4);
+        });
+        sfor<0, M>([&](auto m) {
+          constexpr int MM = m;
+          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MM].x, bv[MM].x, accw[MM], 0, 0, 0);
+        });
+        sfor<0, M>([&](auto m) {
+          constexpr int MM = m;
+          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MM].y, bv[MM].y, accw[MM], 0, 0, 0);
+        });
+        sfor<0, M>([&](auto m) {
+          constexpr int MM = m;
+          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MM].z, bv[MM].z, accw[MM], 0, 0, 0);
+        });
+        sfor<0, M>([&](auto m) {
+          constexpr int MM = m;
+          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MM].w, bv[MM].w, accw[MM], 0, 0, 0);
+        });
+      }
+      PF_PHASE();
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 
   // ---- write-out: tiles -> per-wave padded image in LDS -> fixed-order sum over waves -> partial row -----------
@@ -378,7 +431,7 @@ template <int L, int IN>
 int launch_bwd(const pf_problem* p, int which, hipStream_t s) {
   const int nb = pf_net_blocks(p->mesh.n_elems, p->n_part_blocks);
   constexpr int PADC = pf_pad_count(HP, L);
-  constexpr int row_floats = BW_WAVES * 64 * Row<L>::STRIDE;
+  constexpr int row_floats = BW_WAVES * Row<L>::LEN * Row<L>::CS;
   constexpr int lds_floats = row_floats > BW_WAVES * PADC ? row_floats : BW_WAVES * PADC;
   static_assert(lds_floats * 4 <= 160 * 1024, "LDS budget");
   hipLaunchKernelGGL((k_net44_backward<L, IN>), dim3(nb), dim3(BW_THREADS), lds_floats * sizeof(float), s,

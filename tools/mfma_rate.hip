@@ -78,6 +78,28 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc) {
       v4 = fmaf(v4, a, b); v5 = fmaf(v5, a, b); v6 = fmaf(v6, a, b); v7 = fmaf(v7, a, b); v0 = fmaf(v0, a, b); v1 = fmaf(v1, a, b);
       c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c3, 0, 0, 0);
       v2 = fmaf(v2, a, b); v3 = fmaf(v3, a, b); v4 = fmaf(v4, a, b); v5 = fmaf(v5, a, b); v6 = fmaf(v6, a, b); v7 = fmaf(v7, a, b);
+    } else if (MODE == 9) {   // 8 x 4x4x1 on ONE accumulator (dependent chain)
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 0, 0); c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 1, 0);
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 2, 0); c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 3, 0);
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 4, 0); c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 5, 0);
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 6, 0); c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 7, 0);
+    } else if (MODE == 10) {  // 8 x 4x4x1 on TWO accumulators
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 0, 0); c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c1, 4, 1, 0);
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 2, 0); c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c1, 4, 3, 0);
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 4, 0); c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c1, 4, 5, 0);
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c0, 4, 6, 0); c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c1, 4, 7, 0);
+    } else if (MODE == 11) {  // B operand produced by a VALU op right before each MFMA (4 accs)
+      v0 = fmaf(v0, a, b); c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v0, c0, 4, 0, 0);
+      v1 = fmaf(v1, a, b); c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v1, c1, 4, 1, 0);
+      v2 = fmaf(v2, a, b); c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v2, c2, 4, 2, 0);
+      v3 = fmaf(v3, a, b); c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v3, c3, 4, 3, 0);
+    } else if (MODE == 12) {  // 8 MFMAs then 8 VALU consuming their results (grouped phases)
+      c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v0, c0, 4, 0, 0); c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v1, c1, 4, 1, 0);
+      c2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v2, c2, 4, 2, 0); c3 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v3, c3, 4, 3, 0);
+      c4 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v4, c4, 4, 4, 0); c5 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v5, c5, 4, 5, 0);
+      c6 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v6, c6, 4, 6, 0); c7 = __builtin_amdgcn_mfma_f32_4x4x1f32(a, v7, c7, 4, 7, 0);
+      v0 = fmaf(c0[0], a, b); v1 = fmaf(c1[0], a, b); v2 = fmaf(c2[0], a, b); v3 = fmaf(c3[0], a, b);
+      v4 = fmaf(c4[0], a, b); v5 = fmaf(c5[0], a, b); v6 = fmaf(c6[0], a, b); v7 = fmaf(c7[0], a, b);
     } else if (MODE == 8) {  // transcendental pair exp+rcp x4
       v0 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v0)); v1 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v1));
       v2 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v2)); v3 = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(v3));
@@ -96,7 +118,7 @@ void run(const char* name, int per_iter) {
   float* out; unsigned long long* cyc;
   hipMalloc(&out, 1024 * 256 * sizeof(float));
   hipMallocManaged(&cyc, 256 * sizeof(unsigned long long));
-  for (int waves : {4, 8, 16}) {  // waves per block = per CU (1 block per CU): 1, 2, 4 per SIMD
+  for (int waves : {4, 16}) {  // waves per block = per CU (1 block per CU): 1, 2, 4 per SIMD
     hipLaunchKernelGGL(k<MODE>, dim3(256), dim3(waves * 64), 0, 0, out, cyc);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -122,5 +144,9 @@ int main() {
   run<6>("32x32x2 + 12 v_fma (x2)", 26);
   run<7>("16x16x4 + 6 v_fma (x4)", 28);
   run<8>("exp2+rcp (x4 pairs)", 8);
+  run<9>("4x4x1 chain on 1 acc", 8);
+  run<10>("4x4x1 chain on 2 acc", 8);
+  run<11>("(v_fma -> 4x4x1 B) x4", 8);
+  run<12>("8 mfma then 8 dependent fma", 16);
   return 0;
 }
