@@ -124,7 +124,7 @@ def main():
 
     n_local = args.elems
     lr_t = 5e-4 if args.workload == "ex4" else 1e-3
-    cfg = SolverConfig(max_iterations=args.warmup + args.steps + 8, tolerance=0.0, learning_rate_u=0.01,
+    cfg = SolverConfig(max_iterations=args.warmup + 2 * args.steps + 8, tolerance=0.0, learning_rate_u=0.01,
                        learning_rate_theta=lr_t, alpha_physics=1.0, alpha_data=100.0)
     if world == 1:
         from pinn_fem_amd.engine import HipEngine
@@ -132,14 +132,16 @@ def main():
         eng = HipEngine(model, mv, md, device=dev)
         eng.begin(None, 0.1, cfg, want_history=False)
         run_warm = lambda n: eng.iterate(n)
-        run_timed = lambda n: eng.iterate_timed(n)
+        run_timed = lambda n: eng.iterate(n)          # hipGraph replay (10 iterations per graph)
+        run_events = lambda n: eng.iterate_timed(n)   # eager launches with HIP events around every kernel
     else:
         from pinn_fem_amd.dist import ShardedChainEngine
         widths = {"ex4": (20, 15, 10), "ex3": (20, None, None)}[args.workload]
         eng = ShardedChainEngine(n_local, args.workload, rank, world, dev)
         eng.begin(None, 0.1, cfg)
         run_warm = lambda n: eng.iterate(n)
-        run_timed = lambda n: eng.iterate_timed(n)
+        run_timed = lambda n: eng.iterate(n)
+        run_events = lambda n: eng.iterate_timed(n)
 
     run_warm(args.warmup)
     torch.cuda.synchronize(dev)
@@ -147,7 +149,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    slot_ms = run_timed(args.steps)          # HIP events around every kernel, on the launch stream
+    run_timed(args.steps)                    # EXACTLY K steps: the product path (hipGraph replay)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -159,6 +161,12 @@ def main():
         dt = float(tmax.item())
     st = eng.state()
     assert st.iter == args.warmup + args.steps, (st.iter, args.warmup + args.steps)
+    # the same K steps once more, launched eagerly with a HIP event before every kernel on the launch
+    # stream: per-kernel durations for the roofline (not part of `value`)
+    t1 = time.perf_counter()
+    slot_ms = run_events(args.steps)
+    torch.cuda.synchronize(dev)
+    dt_events = time.perf_counter() - t1
 
     if rank == 0:
         total_elems = n_local * world
@@ -180,6 +188,18 @@ def main():
             roof = {"kernel": names[dom], "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                     "avg_launch_ms": float(slot_ms[dom])}
+        # HBM traffic of the dominant kernel: rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in separate passes,
+        # gfx950 correction applied) of this same command, committed under profiles/
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tr = json.load(f)["kernels"]
+            key = {"net_backward_young": "k_net44_backward:young", "net_backward_area": "k_net44_backward:area",
+                   "node_residual": "k_node_residual<2>", "node_gradu_adam": "k_node_gradu<2, true>"}.get(names[dom])
+            if key in tr and n_local == 1_000_000 and args.workload == "ex4":
+                roof["traffic"] = tr[key]["hbm_bytes_corrected"]
+                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc, per launch)"
+        except Exception:
+            pass
         it_bytes = ALGO_BYTES_PER_EVAL * value / world / 1e9
         roof["iteration_hbm_GBs_per_gpu"] = it_bytes
         roof["iteration_hbm_frac"] = it_bytes / HBM_PEAK_GBS
@@ -193,6 +213,7 @@ def main():
                                    f"{n_local} elements per GPU, collinear 2-D truss h=1, "
                                    f"alpha_data=100 with measurements at every node, load factor 0.1",
                        "elements_total": total_elems, "parallelism": f"elements sharded x{world}"},
+            "ms_per_step_eager_with_events": dt_events / args.steps * 1e3,
             "kernel_ms": {n: float(m) for n, m in zip(names, slot_ms)},
             "roofline": roof,
         }

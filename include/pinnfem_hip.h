@@ -197,6 +197,13 @@ int pf_reset(const pf_problem* p, void* stream);
 /* Enqueue n_iter complete GD iterations (solver.py:254-355).  Once the device-side stop test
  * fires, remaining launches are no-ops, so the final state equals the reference's `break`. */
 int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream);
+/* hipGraph form of pf_gd_iterations: capture `iters_per_graph` iterations once, replay many times
+ * (removes the per-launch host cost and most of the inter-kernel gaps).  The graph bakes in the
+ * pf_problem record by value: create it after the record is final (one per solve_gd call) and destroy
+ * it before changing any field.  *graph_out is an opaque handle owned by the caller. */
+int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void** graph_out);
+int pf_graph_launch(void* graph, void* stream);
+int pf_graph_destroy(void* graph);
 /* Profiling twin of pf_gd_iterations: same launches with a HIP event before every kernel slot, then
  * a stream synchronise; ms_per_kernel (HOST, PF_KERNEL_SLOTS floats) receives the average duration
  * of each slot: 0 net_forward(young) 1 net_forward(area) 2 node_residual 3 elem_adjoint

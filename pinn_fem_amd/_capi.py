@@ -101,6 +101,9 @@ SYMBOLS = {
     "pf_finalize": (C.c_int, [_PP, C.c_void_p]),
     "pf_reset": (C.c_int, [_PP, C.c_void_p]),
     "pf_gd_iterations": (C.c_int, [_PP, C.c_int, C.c_void_p]),
+    "pf_graph_create": (C.c_int, [_PP, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pf_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "pf_graph_destroy": (C.c_int, [C.c_void_p]),
     "pf_gd_iterations_timed": (C.c_int, [_PP, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "pf_loss_and_grads": (C.c_int, [_PP, C.c_void_p]),
     "pf_iface_pack": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -294,6 +294,44 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
   return PF_OK;
 }
 
+int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void** graph_out) {
+  int rc = check_gd(p);
+  if (rc) return rc;
+  if (!graph_out || iters_per_graph < 1) return fail(PF_ERR_ARG, "pf_graph_create: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    return fail(PF_ERR_HIP, "hipStreamBeginCapture failed");
+  for (int i = 0; rc == PF_OK && i < iters_per_graph; ++i) rc = enqueue_iteration(p, 1, 0, s, nullptr);
+  const hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != PF_OK) {
+    if (graph) hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess || !graph) return fail(PF_ERR_HIP, "hipStreamEndCapture failed");
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    hipGraphDestroy(graph);
+    return fail(PF_ERR_HIP, "hipGraphInstantiate failed");
+  }
+  hipGraphDestroy(graph);
+  *graph_out = (void*)exec;
+  return PF_OK;
+}
+
+int pf_graph_launch(void* graph, void* stream) {
+  if (!graph) return fail(PF_ERR_ARG, "null graph");
+  if (hipGraphLaunch((hipGraphExec_t)graph, (hipStream_t)stream) != hipSuccess)
+    return fail(PF_ERR_HIP, "hipGraphLaunch failed");
+  return PF_OK;
+}
+
+int pf_graph_destroy(void* graph) {
+  if (!graph) return PF_OK;
+  if (hipGraphExecDestroy((hipGraphExec_t)graph) != hipSuccess) return fail(PF_ERR_HIP, "hipGraphExecDestroy failed");
+  return PF_OK;
+}
+
 int pf_gd_iterations_timed(const pf_problem* p, int n_iter, void* stream, float* ms_per_kernel) {
   int rc = check_gd(p);
   if (rc) return rc;

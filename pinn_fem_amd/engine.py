@@ -6,7 +6,9 @@ GPU or without the built library construction raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import functools
 import os
 from typing import List, Optional
 
@@ -27,6 +29,16 @@ def _require_gpu(device=None) -> torch.device:
     return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 
 
+def _on_engine_stream(fn):
+    """Run a HipEngine method on the engine's own HIP stream (hipGraph capture is not allowed on the
+    default stream), ordered after the caller's current stream on entry and before it on exit."""
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with self.on_stream():
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class HipEngine:
     """Device-resident problem: mesh plan, flat theta, Adam state, workspaces."""
 
@@ -36,6 +48,7 @@ class HipEngine:
                  iface=None):
         self.lib = _capi.load()
         self.device = _require_gpu(device)
+        self.stream = torch.cuda.Stream(device=self.device)
         self.model = model
         hp = host_plan or build_host_plan(model.nodes, model.elements, model.loads, model.fixed_dofs,
                                           model.dimension, measured_disp, measured_dofs)
@@ -127,17 +140,30 @@ class HipEngine:
         self.hist = torch.zeros(1, **f32)
         self.hist_rows = 0
         self.P = PfProblem()
+        self._graph = None
         self._configured = False
         self.configure(lam=1.0)
 
     # ------------------------------------------------------------------------------------------
     def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return self.stream.cuda_stream
+
+    @contextlib.contextmanager
+    def on_stream(self):
+        outer = torch.cuda.current_stream(self.device)
+        if outer == self.stream:
+            yield
+            return
+        self.stream.wait_stream(outer)
+        with torch.cuda.stream(self.stream):
+            yield
+        outer.wait_stream(self.stream)
 
     def configure(self, lam: float, alpha_physics: float = 1.0, alpha_data: float = 100.0,
                   lr_u: float = 1e-7, lr_t: float = 1e-4, tol: float = 1e-6, max_iter: int = 0,
                   want_history: bool = True, want_grad_u: bool = False):
         """Fill the pf_problem record (scalars of SolverConfig + pointers)."""
+        self._drop_graph()          # a captured graph holds the old record by value
         hp, P = self.plan, self.P
         M = P.mesh
         M.dim, M.n_nodes, M.n_elems, M.n_dofs = hp.dim, hp.n_nodes, hp.n_elems, hp.n_dofs
@@ -189,6 +215,7 @@ class HipEngine:
         return C.byref(self.P)
 
     # ---- solve_gd support ------------------------------------------------------------------------
+    @_on_engine_stream
     def begin(self, u_initial, lam, config, max_iter: Optional[int] = None, want_history=True):
         """Start one solve_gd call: fresh Adam state (solver.py:234-238), u = warm start or 0."""
         if self.n_theta and not self.theta.still_bound():
@@ -209,10 +236,42 @@ class HipEngine:
         _capi.check(self.lib.pf_reset(self._ref(), s), "pf_reset")
         _capi.check(self.lib.pf_pack_theta(self._ref(), s), "pf_pack_theta")
 
-    def iterate(self, n_iter: int):
-        _capi.check(self.lib.pf_gd_iterations(self._ref(), int(n_iter), self._stream()),
-                    "pf_gd_iterations")
+    GRAPH_ITERS = int(os.environ.get("PINNFEM_GRAPH_ITERS", 10))   # iterations per captured hipGraph
 
+    def _drop_graph(self):
+        g = getattr(self, "_graph", None)
+        if g:
+            self.lib.pf_graph_destroy(g)
+        self._graph = None
+
+    @_on_engine_stream
+    def iterate(self, n_iter: int, use_graph: Optional[bool] = None):
+        """Enqueue n_iter GD iterations.  Whole multiples of GRAPH_ITERS replay a captured hipGraph
+        (created lazily per begin(); the graph bakes in the current pf_problem record), the remainder
+        is launched eagerly.  Launches after the device-side stop are no-ops either way."""
+        n_iter = int(n_iter)
+        if use_graph is None:
+            use_graph = os.environ.get("PINNFEM_GRAPH", "1") != "0"
+        s = self._stream()
+        k = self.GRAPH_ITERS
+        if use_graph and n_iter >= k:
+            if getattr(self, "_graph", None) is None:
+                g = C.c_void_p()
+                _capi.check(self.lib.pf_graph_create(self._ref(), k, s, C.byref(g)), "pf_graph_create")
+                self._graph = g
+            while n_iter >= k:
+                _capi.check(self.lib.pf_graph_launch(self._graph, s), "pf_graph_launch")
+                n_iter -= k
+        if n_iter > 0:
+            _capi.check(self.lib.pf_gd_iterations(self._ref(), n_iter, s), "pf_gd_iterations")
+
+    def __del__(self):
+        try:
+            self._drop_graph()
+        except Exception:
+            pass
+
+    @_on_engine_stream
     def iterate_timed(self, n_iter: int) -> np.ndarray:
         """Like iterate() but with HIP events around every kernel; synchronises.  Returns the average
         milliseconds of each kernel slot (_capi.KERNEL_SLOT_NAMES)."""
@@ -221,16 +280,19 @@ class HipEngine:
                     "pf_gd_iterations_timed")
         return np.array(list(out), dtype=np.float64)
 
+    @_on_engine_stream
     def state(self) -> PfState:
         raw = self.state_t.cpu().numpy().tobytes()
         return PfState.from_buffer_copy(raw)
 
+    @_on_engine_stream
     def history(self, n_rows: int) -> np.ndarray:
         if n_rows <= 0 or self.P.hist is None:
             return np.zeros((0, _capi.PF_HIST_COLS), dtype=np.float32)
         return self.hist[: n_rows * _capi.PF_HIST_COLS].cpu().numpy().reshape(n_rows, _capi.PF_HIST_COLS)
 
     # ---- building blocks -------------------------------------------------------------------------
+    @_on_engine_stream
     def eval_properties(self, lam: Optional[float] = None):
         """young/area per element with the current theta (pf_pack_theta + pf_net_forward)."""
         if lam is not None:
@@ -246,6 +308,7 @@ class HipEngine:
         # building-block calls outside a solve_gd run must not be masked by a finished run
         self.state_t[1] = 0
 
+    @_on_engine_stream
     def internal_force(self, u: Optional[torch.Tensor] = None, lam: Optional[float] = None) -> torch.Tensor:
         """f_int = K(theta) u, re-evaluating the nets (the reference's no-grad re-assembly,
         solver.py:374-377)."""
@@ -256,6 +319,7 @@ class HipEngine:
                     "pf_internal_force")
         return out
 
+    @_on_engine_stream
     def loss_and_grads(self, u: torch.Tensor, lam: float, alpha_physics=1.0, alpha_data=100.0):
         """One forward+backward without optimiser step.  Returns (dict of loss terms, grad_u,
         grad_theta) as device tensors (views of engine workspaces)."""
@@ -271,6 +335,7 @@ class HipEngine:
                       residual_norm=st.residual_norm)
         return losses, self.grad_u, self.grad_theta[: max(self.n_theta_active, 0)]
 
+    @_on_engine_stream
     def vjp(self, u: torch.Tensor, g_f: torch.Tensor, lam: float):
         """(K^T g_f, d(g_f . f_int)/dtheta): the backward of f_int = K(theta) u for an arbitrary
         upstream gradient (autograd.Function backward)."""
@@ -296,12 +361,14 @@ class HipEngine:
             _capi.check(lib.pf_theta_reduce(ref, 0, s), "pf_theta_reduce")
         return self.grad_u, self.grad_theta[: max(self.n_theta_active, 0)]
 
+    @_on_engine_stream
     def diag_k(self, lam: Optional[float] = None) -> torch.Tensor:
         self.eval_properties(lam)
         out = torch.empty(self.plan.n_dofs, dtype=torch.float32, device=self.device)
         _capi.check(self.lib.pf_diag_k(self._ref(), out.data_ptr(), self._stream()), "pf_diag_k")
         return out
 
+    @_on_engine_stream
     def dense_k(self, lam: Optional[float] = None) -> torch.Tensor:
         self.eval_properties(lam)
         n = self.plan.n_dofs
