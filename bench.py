@@ -116,11 +116,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    # PINNFEM_BENCH_ONE_GPU=1: rehearsal of the N>1 path on a single GPU (all ranks on cuda:0, gloo
+    # collectives staged through the host) — for testing only, never for reported numbers
+    rehearsal = os.environ.get("PINNFEM_BENCH_ONE_GPU", "0") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n_local = args.elems
     lr_t = 5e-4 if args.workload == "ex4" else 1e-3
@@ -156,7 +164,7 @@ def main():
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st = eng.state()
@@ -208,7 +216,8 @@ def main():
                       "assembly, residual, Adam), collinear truss",
             "value": value, "unit": "element-evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (ONE-GPU REHEARSAL: not a valid multi-GPU number)" if rehearsal else ""),
             "config": {"workload": f"{args.workload} shape (nets {widths}, E and A evaluated), "
                                    f"{n_local} elements per GPU, collinear 2-D truss h=1, "
                                    f"alpha_data=100 with measurements at every node, load factor 0.1",
