@@ -235,6 +235,18 @@ int pf_adam_theta(const pf_problem* p, void* stream);
  * and sum_u2 (dev, 1 float) */
 int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* sum_u2, void* stream);
 
+/* The same steps grouped between the three collectives of one sharded iteration, so the host makes
+ * four calls per iteration instead of ~20 (pinn_fem_amd/dist.py):
+ *   phase1: nets forward, node_residual (f_int -> fbuf), pack f_int interface        -> all-reduce(iface1)
+ *   phase2: fix residual, element adjoint, nets backward, node_gradu, theta reduce (into
+ *           p->grad_theta, which the host points inside buf2), pack grad_u interface,
+ *           local sums -> buf2 = [iface | grad_theta | r2, d2, -]                     -> all-reduce(buf2)
+ *   phase3: unpack grad_u interface, Adam(u)+clamp, Adam(theta), local sums -> u2[3]  -> all-reduce(u2)
+ *   phase4: pf_finalize_from(buf2 tail, u2+2) */
+int pf_shard_phase1(const pf_problem* p, float* fbuf, float* iface1, void* stream);
+int pf_shard_phase2(const pf_problem* p, const float* iface1, float* buf2, void* stream);
+int pf_shard_phase3(const pf_problem* p, const float* buf2, float* u2, void* stream);
+
 /* ---- extensions (off the default path) ------------------------------------------------ */
 /* generic Adam (torch.optim.Adam single-tensor arithmetic) on a flat vector */
 int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step,

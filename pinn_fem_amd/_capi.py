@@ -113,6 +113,9 @@ SYMBOLS = {
     "pf_adam_u": (C.c_int, [_PP, C.c_void_p]),
     "pf_adam_theta": (C.c_int, [_PP, C.c_void_p]),
     "pf_finalize_from": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_shard_phase1": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_shard_phase2": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_shard_phase3": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pf_diag_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),

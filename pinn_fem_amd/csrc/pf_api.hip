@@ -436,6 +436,49 @@ int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* s
   return PF_OK;
 }
 
+int pf_shard_phase1(const pf_problem* p, float* fbuf, float* iface1, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!fbuf || !iface1) return fail(PF_ERR_ARG, "null fbuf / iface1");
+  hipStream_t s = (hipStream_t)stream;
+  for (int k = 0; k < 2; ++k)
+    if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+  PF_TRY(pf_launch_node_residual(p, fbuf, 1, s), "node_residual");
+  PF_TRY(pf_launch_iface_pack(p, fbuf, iface1, s), "iface_pack");
+  return PF_OK;
+}
+
+int pf_shard_phase2(const pf_problem* p, const float* iface1, float* buf2, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!iface1 || !buf2 || !p->grad_u) return fail(PF_ERR_ARG, "null iface1 / buf2 / grad_u");
+  hipStream_t s = (hipStream_t)stream;
+  const bool any_net = p->net[0].enabled || p->net[1].enabled;
+  PF_TRY(pf_launch_iface_fix_residual(p, iface1, s), "iface_fix_residual");
+  if (any_net) {
+    PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+    for (int k = 0; k < 2; ++k)
+      if (p->net[k].enabled) PF_TRY(net_backward(p, k, s), "net_backward");
+  }
+  PF_TRY(pf_launch_node_gradu(p, 0, s), "node_gradu");
+  if (any_net) PF_TRY(pf_launch_theta_reduce(p, 0, s), "theta_reduce");
+  PF_TRY(pf_launch_iface_pack(p, p->grad_u, buf2, s), "iface_pack");
+  PF_TRY(pf_launch_local_sums(p, buf2 + p->n_iface + p->n_theta_active, s), "local_sums");
+  return PF_OK;
+}
+
+int pf_shard_phase3(const pf_problem* p, const float* buf2, float* u2, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!buf2 || !u2 || !p->grad_u || !p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null buffer");
+  hipStream_t s = (hipStream_t)stream;
+  PF_TRY(pf_launch_iface_unpack(p, buf2, p->grad_u, s), "iface_unpack");
+  PF_TRY(pf_launch_adam_u(p, s), "adam_u");
+  PF_TRY(pf_launch_adam_theta(p, s), "adam_theta");
+  PF_TRY(pf_launch_local_sums(p, u2, s), "local_sums");
+  return PF_OK;
+}
+
 int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,
             double beta1, double beta2, double eps, void* stream) {
   if (!param || !grad || !m || !v || n < 0 || step < 1) return fail(PF_ERR_ARG, "pf_adam: bad argument");

@@ -226,57 +226,31 @@ class HipShardBackend(ShardBackend):
     def history(self, n):
         return self.eng.history(n)
 
-    # -- ShardBackend -------------------------------------------------------------------------------
-    def _call(self, fn, *args):
-        e = self.eng
-        _capi.check(fn(e._ref(), *args, e._stream()), fn.__name__ if hasattr(fn, "__name__") else "pf")
-
+    # -- ShardBackend: one C call per phase (pf_shard_phase1..3, pf_finalize_from) ------------------------
     def forward_residual(self):
-        e, lib = self.eng, self.eng.lib
-        s, ref = e._stream(), e._ref()
-        for k, spec in enumerate(e.specs):
-            if spec.enabled:
-                _capi.check(lib.pf_net_forward(ref, k, s), "pf_net_forward")
-        _capi.check(lib.pf_node_residual(ref, self.fbuf.data_ptr(), s), "pf_node_residual")
+        pass                                   # done together with the interface pack in pack_f()
 
     def pack_f(self, iface):
         e = self.eng
-        _capi.check(e.lib.pf_iface_pack(e._ref(), self.fbuf.data_ptr(), iface.data_ptr(), e._stream()),
-                    "pf_iface_pack")
+        _capi.check(e.lib.pf_shard_phase1(e._ref(), self.fbuf.data_ptr(), iface.data_ptr(), e._stream()),
+                    "pf_shard_phase1")
 
     def fix_residual(self, iface):
-        e = self.eng
-        _capi.check(e.lib.pf_iface_fix_residual(e._ref(), iface.data_ptr(), e._stream()),
-                    "pf_iface_fix_residual")
+        self._if1_ptr = iface.data_ptr()       # consumed at the start of phase 2
 
     def backward(self, buf2):
-        e, lib = self.eng, self.eng.lib
-        s = e._stream()
-        # gradients of theta are reduced straight into the collective buffer
+        e = self.eng
         if self._buf2_ptr != buf2.data_ptr():
+            # gradients of theta are reduced straight into the collective buffer
             self._buf2_ptr = buf2.data_ptr()
             e.P.grad_theta = buf2.data_ptr() + 4 * self.n_iface
-        ref = e._ref()
-        any_net = any(sp.enabled for sp in e.specs)
-        if any_net:
-            _capi.check(lib.pf_elem_adjoint(ref, s), "pf_elem_adjoint")
-            for k, spec in enumerate(e.specs):
-                if spec.enabled:
-                    _capi.check(lib.pf_net_backward(ref, k, s), "pf_net_backward")
-        _capi.check(lib.pf_node_gradu(ref, 0, s), "pf_node_gradu")
-        if any_net:
-            _capi.check(lib.pf_theta_reduce(ref, 0, s), "pf_theta_reduce")
-        _capi.check(lib.pf_iface_pack(ref, e.grad_u.data_ptr(), buf2.data_ptr(), s), "pf_iface_pack")
-        _capi.check(lib.pf_local_sums(ref, buf2.data_ptr() + 4 * (self.n_iface + self.n_theta_active), s),
-                    "pf_local_sums")
+        _capi.check(e.lib.pf_shard_phase2(e._ref(), self._if1_ptr, buf2.data_ptr(), e._stream()),
+                    "pf_shard_phase2")
 
     def update(self, buf2, u2):
-        e, lib = self.eng, self.eng.lib
-        s, ref = e._stream(), e._ref()
-        _capi.check(lib.pf_iface_unpack(ref, buf2.data_ptr(), e.grad_u.data_ptr(), s), "pf_iface_unpack")
-        _capi.check(lib.pf_adam_u(ref, s), "pf_adam_u")
-        _capi.check(lib.pf_adam_theta(ref, s), "pf_adam_theta")
-        _capi.check(lib.pf_local_sums(ref, u2.data_ptr(), s), "pf_local_sums")
+        e = self.eng
+        _capi.check(e.lib.pf_shard_phase3(e._ref(), buf2.data_ptr(), u2.data_ptr(), e._stream()),
+                    "pf_shard_phase3")
 
     def finalize(self, r2d2, u2):
         e = self.eng

@@ -378,3 +378,48 @@ def test_api_pinn_gd_identifies_stiffness(tmp_path):
     assert np.max(np.abs(u[[2, 4, 6]] - [0.5, 1.0, 1.5])) < 0.05
     assert out["convergence_history"][0]["loss_total"] > out["final_loss"]
     assert len(out["convergence_history"]) == 150
+
+
+@pytest.mark.parametrize("wg", [2, 1])
+@pytest.mark.parametrize("width,layers,dim", [(1, 1, 2), (4, 1, 2), (7, 2, 2), (8, 3, 2), (12, 2, 1), (16, 2, 2),
+                                                (20, 3, 2), (24, 2, 2), (28, 1, 1), (32, 2, 2), (32, 3, 1), (15, 2, 2)])
+def test_net_shape_menu(width, layers, dim, wg):
+    """Every padded width (4..32), 1..3 hidden layers, 1-D (input [load_factor, x]) and 2-D meshes:
+    HIP vs oracle on a 150-element mesh with a different net shape for E and A."""
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.properties import NNProperty
+    from pinn_fem_amd.nets import SimpleNN
+    n = 150
+    rng = np.random.default_rng(width * 10 + layers)
+    in_dim = dim + 1
+    torch.manual_seed(width + 100 * layers)
+    net_e = SimpleNN(layers, width, in_dim)
+    net_a = SimpleNN(max(1, layers - 1) if layers > 1 else 2, max(2, width // 2), in_dim)
+    th_e = [p.detach().numpy().copy() for p in net_e.parameters()]
+    th_a = [p.detach().numpy().copy() for p in net_a.parameters()]
+    if dim == 2:
+        ang = np.cumsum(rng.uniform(-0.3, 0.3, n))
+        pts = np.concatenate([[[0.0, 0.0]], np.cumsum(np.stack([np.cos(ang), np.sin(ang)], 1) * 0.1, 0)])
+        nodes = pts
+        fixed = np.array([0, 1])
+    else:
+        nodes = np.concatenate([[0.0], np.cumsum(rng.uniform(0.05, 0.15, n))])
+        fixed = np.array([0])
+    elements = np.stack([np.arange(n), np.arange(1, n + 1)], 1)
+    ndof = (n + 1) * dim
+    loads = rng.normal(size=ndof) * 0.1
+    u = (rng.normal(size=ndof) * 0.02).astype(np.float32)
+    u[fixed] = 0
+    md = rng.choice(np.arange(dim, ndof), size=40, replace=False)
+    mv = rng.normal(size=40) * 0.02
+    model = FEMModel(nodes, elements, Material(NNProperty(net_e, in_dim, True, 1.5), NNProperty(net_a, in_dim, True, 0.7)),
+                     loads, fixed, dimension=dim)
+    pb = orc.Problem(nodes=nodes, elements=elements, loads=loads, fixed_dofs=fixed, dimension=dim,
+                     young=orc.NetParams(th_e, 1.5), area=orc.NetParams(th_a, 0.7), measured_vals=mv, measured_dofs=md)
+    ref = orc.loss_and_grads(pb, orc.element_geometry(pb), u, 0.45, 1.0, 50.0)
+    eng = _engine(model, mv, md, wg)
+    losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.45, 1.0, 50.0)
+    assert abs(losses["loss_total"] - ref.loss_total) < 2e-5 * abs(ref.loss_total)
+    assert rel_err(gu.cpu().numpy(), ref.grad_u) < 3e-5
+    ref_t = np.concatenate([g.reshape(-1) for g in ref.grad_theta])
+    assert rel_err(gt.cpu().numpy(), ref_t) < 1e-4
