@@ -12,6 +12,7 @@ int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s);
 int pf_launch_pack_theta(const pf_problem* p, hipStream_t s);
 int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s);
 int pf_launch_theta_stage1(const pf_problem* p, hipStream_t s);
+int pf_launch_theta_stage2(const pf_problem* p, int fuse_adam, hipStream_t s);
 int pf_launch_reset(const pf_problem* p, hipStream_t s);
 int pf_launch_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,
                    double beta1, double beta2, double eps, hipStream_t s);
@@ -99,6 +100,15 @@ static int net_backward(const pf_problem* p, int which, hipStream_t s) {
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_backward_) }
   PF_WIDTH_SWITCH(pf_launch_net_backward_)
 }
+
+// backward that also computes and stores the element adjoint g_ea (MFMA44 engine only)
+static int net_backward_gea(const pf_problem* p, int which, hipStream_t s) {
+  PF_WIDTH_SWITCH(pf_launch_net44_backward_gea_)
+}
+
+// element adjoint + backward of every enabled net; with the MFMA44 engine the adjoint is fused into
+// the first net's backward kernel
+
 
 #define PF_TRY(expr, what)                       \
   do {                                           \
@@ -258,12 +268,16 @@ static int enqueue_iteration(const pf_problem* p, int fuse_adam, int finalize_mo
   if (p->net[1].enabled) PF_TRY(net_forward(p, 1, s), "net_forward");
   PF_MARK(K_RESIDUAL);
   PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
+  const bool fuse_gea = any_net && p->wg_mode == PF_WG_MFMA44;
+  const int first = p->net[0].enabled ? 0 : 1;
   PF_MARK(K_ADJOINT);
-  if (any_net) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+  if (any_net && !fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
   PF_MARK(K_BWD_E);
-  if (p->net[0].enabled) PF_TRY(net_backward(p, 0, s), "net_backward");
+  if (p->net[0].enabled)
+    PF_TRY(fuse_gea && first == 0 ? net_backward_gea(p, 0, s) : net_backward(p, 0, s), "net_backward");
   PF_MARK(K_BWD_A);
-  if (p->net[1].enabled) PF_TRY(net_backward(p, 1, s), "net_backward");
+  if (p->net[1].enabled)
+    PF_TRY(fuse_gea && first == 1 ? net_backward_gea(p, 1, s) : net_backward(p, 1, s), "net_backward");
   PF_MARK(K_GRADU);
   PF_TRY(pf_launch_node_gradu(p, fuse_adam, s), "node_gradu");
   PF_MARK(K_THETA);
@@ -294,6 +308,33 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
   return PF_OK;
 }
 
+// One iteration with the parameter-gradient tail on a side stream (only meaningful while capturing a
+// graph): [theta stage 1, stage 2 + Adam(theta)] run beside [node_gradu + Adam(u)]; both join before
+// the monitors.  Neither branch reads what the other writes.
+static int enqueue_iteration_forked(const pf_problem* p, hipStream_t s, hipStream_t side, hipEvent_t e_fork,
+                                    hipEvent_t e_join) {
+  const bool any_net = p->net[0].enabled || p->net[1].enabled;
+  if (!any_net) return enqueue_iteration(p, 1, 0, s, nullptr);
+  const bool fuse_gea = p->wg_mode == PF_WG_MFMA44;
+  const int first = p->net[0].enabled ? 0 : 1;
+  for (int k = 0; k < 2; ++k)
+    if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+  PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
+  if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+  for (int k = 0; k < 2; ++k)
+    if (p->net[k].enabled)
+      PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
+  if (hipEventRecord(e_fork, s) != hipSuccess || hipStreamWaitEvent(side, e_fork, 0) != hipSuccess)
+    return fail(PF_ERR_HIP, "graph fork failed");
+  PF_TRY(pf_launch_theta_stage1(p, side), "theta_stage1");
+  PF_TRY(pf_launch_theta_stage2(p, 1, side), "theta_stage2");
+  PF_TRY(pf_launch_node_gradu(p, 1, s), "node_gradu");
+  if (hipEventRecord(e_join, side) != hipSuccess || hipStreamWaitEvent(s, e_join, 0) != hipSuccess)
+    return fail(PF_ERR_HIP, "graph join failed");
+  PF_TRY(pf_launch_finalize(p, 0, 0, s), "finalize");
+  return PF_OK;
+}
+
 int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void** graph_out) {
   int rc = check_gd(p);
   if (rc) return rc;
@@ -301,10 +342,31 @@ int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void
   hipStream_t s = (hipStream_t)stream;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+  hipStream_t side = nullptr;
+  const int nev = 2 * iters_per_graph;
+  hipEvent_t* ev = new hipEvent_t[nev];
+  int made = 0;
+  bool ok = hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess;
+  for (; ok && made < nev; ++made)
+    if (hipEventCreateWithFlags(&ev[made], hipEventDisableTiming) != hipSuccess) break;
+  ok = ok && made == nev;
+  auto cleanup = [&]() {
+    for (int i = 0; i < made; ++i) hipEventDestroy(ev[i]);
+    delete[] ev;
+    if (side) hipStreamDestroy(side);
+  };
+  if (!ok) {
+    cleanup();
+    return fail(PF_ERR_HIP, "pf_graph_create: stream/event creation failed");
+  }
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    cleanup();
     return fail(PF_ERR_HIP, "hipStreamBeginCapture failed");
-  for (int i = 0; rc == PF_OK && i < iters_per_graph; ++i) rc = enqueue_iteration(p, 1, 0, s, nullptr);
+  }
+  for (int i = 0; rc == PF_OK && i < iters_per_graph; ++i)
+    rc = enqueue_iteration_forked(p, s, side, ev[2 * i], ev[2 * i + 1]);
   const hipError_t e = hipStreamEndCapture(s, &graph);
+  cleanup();
   if (rc != PF_OK) {
     if (graph) hipGraphDestroy(graph);
     return rc;
@@ -456,9 +518,12 @@ int pf_shard_phase2(const pf_problem* p, const float* iface1, float* buf2, void*
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
   PF_TRY(pf_launch_iface_fix_residual(p, iface1, s), "iface_fix_residual");
   if (any_net) {
-    PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+    const bool fuse_gea = p->wg_mode == PF_WG_MFMA44;
+    const int first = p->net[0].enabled ? 0 : 1;
+    if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
     for (int k = 0; k < 2; ++k)
-      if (p->net[k].enabled) PF_TRY(net_backward(p, k, s), "net_backward");
+      if (p->net[k].enabled)
+        PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
   }
   PF_TRY(pf_launch_node_gradu(p, 0, s), "node_gradu");
   if (any_net) PF_TRY(pf_launch_theta_reduce(p, 0, s), "theta_reduce");

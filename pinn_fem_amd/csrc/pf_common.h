@@ -100,6 +100,95 @@ __device__ __forceinline__ float pf_softplus_grad(float z) {
   return ez * __builtin_amdgcn_rcpf(ez + 1.f);
 }
 
+// ---- element algebra shared by the node kernels and the fused backward ---------------------------
+struct ElemGeo { float c2, cs, s2, l0; };
+
+__device__ __forceinline__ ElemGeo load_geo(const float* __restrict__ egeo, int e) {
+  const float4 g = reinterpret_cast<const float4*>(egeo)[e];
+  return ElemGeo{g.x, g.y, g.z, g.w};
+}
+
+__device__ __forceinline__ float elem_stiffness(const pf_problem& P, int e, float l0) {
+  const float E = P.net[0].enabled ? P.prop_e[e] : P.net[0].scale;
+  const float A = P.net[1].enabled ? P.prop_a[e] : P.net[1].scale;
+  return (E * A) / l0;  // nn_assembly.py:74 (2-D), :37 (1-D)
+}
+
+// rows `2*end`, `2*end+1` of (s*pattern) @ [v_i; v_j].
+// mode PF_FE_REFERENCE: the reference's operation order, a 4-term dot per row with b ascending
+//   (nn_assembly.py:96-100): s*c2*v_ix + s*cs*v_iy - s*c2*v_jx - s*cs*v_jy.  With |v| >> |v_j - v_i|
+//   (long chains) this cancels in float32 exactly like the reference does.
+// mode PF_FE_DELTA: the same product written on d = v_j - v_i (mathematically identical, no
+//   cancellation); not the reference's round-off, so it is opt-in.
+template <int DIM>
+__device__ __forceinline__ void ke_rows_times(const ElemGeo& g, float s, int end, const float* vi,
+                                              const float* vj, float* out, int mode) {
+  const float sg = end ? -1.f : 1.f;  // rows 2,3 are the exactly negated rows 0,1
+  if (DIM == 2) {
+    if (mode == PF_FE_DELTA) {
+      const float d0 = vj[0] - vi[0], d1 = vj[1] - vi[1];
+      const float q0 = fmaf(g.cs, d1, g.c2 * d0), q1 = fmaf(g.s2, d1, g.cs * d0);
+      out[0] = (-(sg * s)) * q0;
+      out[1] = (-(sg * s)) * q1;
+      return;
+    }
+    const float k_c2 = s * g.c2, k_cs = s * g.cs, k_s2 = s * g.s2;
+    // row 0: [ c2, cs, -c2, -cs ]   row 1: [ cs, s2, -cs, -s2 ]
+    float r0 = (sg * k_c2) * vi[0];
+    r0 = fmaf(sg * k_cs, vi[1], r0);
+    r0 = fmaf(-(sg * k_c2), vj[0], r0);
+    r0 = fmaf(-(sg * k_cs), vj[1], r0);
+    float r1 = (sg * k_cs) * vi[0];
+    r1 = fmaf(sg * k_s2, vi[1], r1);
+    r1 = fmaf(-(sg * k_cs), vj[0], r1);
+    r1 = fmaf(-(sg * k_s2), vj[1], r1);
+    out[0] = r0;
+    out[1] = r1;
+  } else {
+    if (mode == PF_FE_DELTA) {
+      out[0] = (-(sg * s)) * (vj[0] - vi[0]);
+      return;
+    }
+    float r0 = (sg * s) * vi[0];  // [[1,-1],[-1,1]]
+    r0 = fmaf(-(sg * s), vj[0], r0);
+    out[0] = r0;
+  }
+}
+
+template <int DIM>
+__device__ __forceinline__ void load_vec(const float* __restrict__ v, int node, float* out) {
+  if (DIM == 2) {
+    const float2 t = reinterpret_cast<const float2*>(v)[node];
+    out[0] = t.x;
+    out[1] = t.y;
+  } else {
+    out[0] = v[node];
+  }
+}
+
+// dL/d(E*A) of element e: g_s / l0 with g_s = sum_ab g_fe[a] pattern[a][b] u[b]
+// (autograd through ke = s*pattern, fe = ke@u_e, s = (E*A)/l0: nn_assembly.py:74, 96-100)
+template <int DIM>
+__device__ __forceinline__ float pf_elem_gea(const pf_problem& P, int e) {
+  const pf_mesh& M = P.mesh;
+  const int2 nn = reinterpret_cast<const int2*>(M.conn)[e];
+  const ElemGeo g = load_geo(M.egeo, e);
+  float ui[2], uj[2], gi[2], gj[2], pu0[2], pu1[2];
+  load_vec<DIM>(P.u, nn.x, ui);
+  load_vec<DIM>(P.u, nn.y, uj);
+  load_vec<DIM>(P.g_f, nn.x, gi);
+  load_vec<DIM>(P.g_f, nn.y, gj);
+  // (pattern @ u_e): rows 0,1 (end 0) and rows 2,3 (end 1) with unit stiffness
+  ke_rows_times<DIM>(g, 1.f, 0, ui, uj, pu0, P.fe_mode);
+  ke_rows_times<DIM>(g, 1.f, 1, ui, uj, pu1, P.fe_mode);
+  float gs = 0.f;
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) gs = fmaf(gi[c], pu0[c], gs);
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) gs = fmaf(gj[c], pu1[c], gs);
+  return gs / g.l0;  // div backward of (young*area)/l0
+}
+
 // blocks the element-parallel net kernels launch for n elements
 __host__ __device__ inline int pf_net_blocks(int n_elems, int n_part_blocks) {
   int nb = (n_elems + PF_NET_THREADS - 1) / PF_NET_THREADS;
@@ -120,7 +209,8 @@ __host__ __device__ inline int pf_node_blocks(int n_nodes, int n_part_blocks) {
   int pf_launch_net_forward_##HP(const pf_problem* p, int which, hipStream_t s);          \
   int pf_launch_net_backward_##HP(const pf_problem* p, int which, hipStream_t s);          \
   int pf_launch_net44_forward_##HP(const pf_problem* p, int which, hipStream_t s);        \
-  int pf_launch_net44_backward_##HP(const pf_problem* p, int which, hipStream_t s);
+  int pf_launch_net44_backward_##HP(const pf_problem* p, int which, hipStream_t s);       \
+  int pf_launch_net44_backward_gea_##HP(const pf_problem* p, int which, hipStream_t s);
 PF_DECL_NET_LAUNCHERS(4)
 PF_DECL_NET_LAUNCHERS(8)
 PF_DECL_NET_LAUNCHERS(12)

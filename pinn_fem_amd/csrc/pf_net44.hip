@@ -228,7 +228,9 @@ struct Row {
 constexpr int BW_THREADS = PF_NET_THREADS;
 constexpr int BW_WAVES = BW_THREADS / 64;
 
-template <int L, int IN>
+// GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the
+// other net's backward: saves the separate k_elem_adjoint pass in the fused iteration.
+template <int L, int IN, bool GEA>
 __global__ __launch_bounds__(BW_THREADS, (L <= 2 ? 3 : 2)) void k_net44_backward(pf_problem P, int which) {
   if (P.state->done) return;
   extern __shared__ __align__(16) float lds[];
@@ -286,7 +288,14 @@ __global__ __launch_bounds__(BW_THREADS, (L <= 2 ? 3 : 2)) void k_net44_backward
     float gz = 0.f;
     if (live) {
       const float oth = onet.enabled ? other[e] : onet.scale;
-      float g = g_ea[e] * oth;   // mul backward of young*area        (nn_assembly.py:74)
+      float gea;
+      if (GEA) {
+        gea = pf_elem_gea<IN - 1>(P, e);
+        P.g_ea[e] = gea;
+      } else {
+        gea = g_ea[e];
+      }
+      float g = gea * oth;       // mul backward of young*area        (nn_assembly.py:74)
       g = g * net.scale;         // output*scale backward              (properties.py:156)
       gz = net.positive ? g * pf_softplus_grad(z) : g;
     }
@@ -427,17 +436,21 @@ int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 
-template <int L, int IN>
-int launch_bwd(const pf_problem* p, int which, hipStream_t s) {
+template <int L, int IN, bool GEA>
+int launch_bwd_t(const pf_problem* p, int which, hipStream_t s) {
   const int nb = pf_net_blocks(p->mesh.n_elems, p->n_part_blocks);
   constexpr int PADC = pf_pad_count(HP, L);
   constexpr int row_floats = BW_WAVES * Row<L>::LEN * Row<L>::CS;
   constexpr int lds_floats = row_floats > BW_WAVES * PADC ? row_floats : BW_WAVES * PADC;
   static_assert(lds_floats * 4 <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((k_net44_backward<L, IN>), dim3(nb), dim3(BW_THREADS), lds_floats * sizeof(float), s,
+  hipLaunchKernelGGL((k_net44_backward<L, IN, GEA>), dim3(nb), dim3(BW_THREADS), lds_floats * sizeof(float), s,
                      *p, which);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
+template <int L, int IN>
+int launch_bwd(const pf_problem* p, int which, hipStream_t s) { return launch_bwd_t<L, IN, false>(p, which, s); }
+template <int L, int IN>
+int launch_bwd_gea(const pf_problem* p, int which, hipStream_t s) { return launch_bwd_t<L, IN, true>(p, which, s); }
 
 }  // namespace
 
@@ -461,4 +474,7 @@ int PF_CAT(pf_launch_net44_forward_, PF_HP)(const pf_problem* p, int which, hipS
 }
 int PF_CAT(pf_launch_net44_backward_, PF_HP)(const pf_problem* p, int which, hipStream_t s) {
   PF_DISPATCH(launch_bwd)
+}
+int PF_CAT(pf_launch_net44_backward_gea_, PF_HP)(const pf_problem* p, int which, hipStream_t s) {
+  PF_DISPATCH(launch_bwd_gea)
 }
