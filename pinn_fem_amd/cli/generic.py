@@ -73,6 +73,15 @@ def parse_problem(problem_file):
     with open(problem_file, "r") as f:
         data = json.load(f)
 
+    # ---- build-only extension, namespaced so that reference JSONs stay valid -----------
+    # "accel": {"synthetic_chain": {"n_elements": N, "h": 1.0, "tip_load": 1.0},   mesh generator
+    #           "compact_output": true|false|"auto",  big arrays -> <stem>.res.npz instead of JSON lists
+    #           "fe_mode": "reference"|"delta"}       element-force formulation
+    accel = data.get("accel", {})
+    chain = accel.get("synthetic_chain")
+    if chain and not data.get("nodes"):
+        return _parse_synthetic_chain(data, accel, chain)
+
     nodes_list = data.get("nodes", [])
     if nodes_list and isinstance(nodes_list[0], list):           # :155-164
         nodes_array = np.array(nodes_list, dtype=float)
@@ -154,7 +163,19 @@ def parse_problem(problem_file):
     model = FEMModel(nodes=nodes, elements=elements, material=material, loads=f_ext,
                      fixed_dofs=fixed_dofs, dimension=problem_dim)
 
-    sc, pc = data.get("solver_config", {}), data.get("pinn_config", {})   # :377-428
+    solver_config = _solver_config_from(data)                                 # :377-428
+    log_print(f"[DEBUG] Solver config: method={solver_config.method}, tol={solver_config.tolerance}, "
+              f"max_iter={solver_config.max_iterations}", level="debug")
+    log_print("[DEBUG] parse_problem completed successfully", level="debug")
+    if accel.get("fe_mode") == "delta":
+        model._pf_fe_mode = 1
+    return {"model": model, "solver_config": solver_config, "measured_data": measured_data,
+            "accel": accel}
+
+
+def _solver_config_from(data):
+    """SolverConfig with the reference's precedence rules (generic.py:377-428)."""
+    sc, pc = data.get("solver_config", {}), data.get("pinn_config", {})
     solver_type = data.get("solver_type", "auto")
     explicit = sc.get("method", None)
     if explicit:
@@ -167,7 +188,7 @@ def parse_problem(problem_file):
         method = "hybrid"
     else:
         method = "auto"
-    solver_config = SolverConfig(
+    return SolverConfig(
         max_iterations=pc.get("max_iterations", sc.get("max_iterations", 1000)),
         tolerance=pc.get("tolerance", sc.get("tolerance", 1e-6)),
         print_every=pc.get("print_every", 10),
@@ -179,10 +200,35 @@ def parse_problem(problem_file):
         alpha_data=pc.get("alpha_data", 100.0),
         preconditioning=pc.get("preconditioning", sc.get("preconditioning", False)),
         method=method)
-    log_print(f"[DEBUG] Solver config: method={solver_config.method}, tol={solver_config.tolerance}, "
-              f"max_iter={solver_config.max_iterations}", level="debug")
-    log_print("[DEBUG] parse_problem completed successfully", level="debug")
-    return {"model": model, "solver_config": solver_config, "measured_data": measured_data}
+
+
+def _parse_synthetic_chain(data, accel, chain):
+    """Mesh generator for large runs (SURVEY.md §8(d) inputs, §8(f) rank 2): collinear 2-D truss with
+    nodes (i*h, 0), elements (e, e+1), node 0 ux fixed and every uy fixed, tip load, measurements
+    ux_i = x_i / uy_i = 0 at every node >= 1 — the shape of the reference's example3/4 at any size,
+    without a 100 MB node list in the JSON."""
+    from ..plan import chain_mesh
+    n = int(chain["n_elements"])
+    h = float(chain.get("h", 1.0))
+    nodes, elements, loads, fixed, mv, md = chain_mesh(n, h)
+    loads[2 * n] = float(chain.get("tip_load", 1.0))
+    material_data = data.get("material", {})
+    base = {"young": material_data.get("young", 210e9), "area": material_data.get("area", 0.01),
+            "density": material_data.get("density", 7850)}
+    nn_config = data.get("nn_config", {})
+    material = Material(young=_make_property("young", nn_config, base["young"]),
+                        area=_make_property("area", nn_config, base["area"]),
+                        density=_make_property("density", nn_config, base["density"]))
+    model = FEMModel(nodes=nodes, elements=elements, material=material, loads=loads, fixed_dofs=fixed,
+                     dimension=2)
+    if accel.get("fe_mode") == "delta":
+        model._pf_fe_mode = 1
+    measured = {}
+    if data.get("solver_type", "fem").startswith("pinn") and chain.get("measure_every_node", True):
+        measured = {"dofs": md, "values": mv}
+    log_print(f"[DEBUG] synthetic chain: {n} elements, h={h}", level="debug")
+    return {"model": model, "solver_config": _solver_config_from(data), "measured_data": measured,
+            "accel": accel}
 
 
 def _eval_points(prop: NNProperty, pts: np.ndarray, lf, dimension: int) -> list:
@@ -256,14 +302,35 @@ def solve_problem(parsed_data):
     result = solve(model=model, config=solver_config,
                    measured_disp=measured_data.get("values", None),
                    measured_dofs=measured_data.get("dofs", None))
+    compact = parsed_data.get("accel", {}).get("compact_output", "auto")
+    if compact == "auto":
+        compact = model.nnode > 50_000
     output = {
         "success": result.converged,
         "converged": result.converged,
         "iterations": len(result.history),
-        "displacements": result.displacements.flatten().tolist(),
-        "reactions": result.reactions.flatten().tolist() if result.reactions is not None else [],
         "history": result.history,
     }
+    if compact:
+        # §8(f) rank 1: at 10^6 nodes the reference's JSON lists (every coordinate three times per
+        # property) would be hundreds of MB; arrays go to a side file, the JSON keeps the small fields
+        arrays = {"displacements": result.displacements.flatten(),
+                  "reactions": result.reactions.flatten()}
+        if result.nn_parameters:
+            output["nn_parameters"] = {k: v.tolist() for k, v in result.nn_parameters.items()}
+            cent = (model.nodes[model.elements[:, 0]] + model.nodes[model.elements[:, 1]]) / 2.0
+            for name in ("young", "area", "density"):
+                prop = getattr(model.material, name)
+                if hasattr(prop, "net"):
+                    for lf in (0.2, 0.5, 1.0):
+                        arrays[f"{name}_at_elements_lf{lf:.1f}"] = np.asarray(
+                            _eval_points(prop, cent, lf if prop.input_dim > model.dimension else None,
+                                         model.dimension), dtype=np.float32)
+        output["arrays_npz"] = "__SIDE_FILE__"
+        output["_arrays"] = arrays
+        return output
+    output["displacements"] = result.displacements.flatten().tolist()
+    output["reactions"] = result.reactions.flatten().tolist() if result.reactions is not None else []
     if result.nn_parameters:
         output["nn_parameters"] = {k: v.tolist() for k, v in result.nn_parameters.items()}
         output["identified_properties"] = extract_nn_properties(model)
@@ -292,6 +359,12 @@ def main(argv=None):
         result = solve_problem(parsed)
         log_print("[OK] Problem solved")
         log_print("\n[STEP 3] Writing results...")
+        arrays = result.pop("_arrays", None)
+        if arrays is not None:
+            side = str(Path(output_file).with_suffix("")) + ".npz"
+            np.savez(side, **arrays)
+            result["arrays_npz"] = Path(side).name
+            result["displacement_abs_max"] = float(np.max(np.abs(arrays["displacements"])))
         with open(output_file, "w") as f:
             json.dump(result, f, indent=2)
         log_print(f"[OK] Results written to {output_file}")
@@ -300,7 +373,9 @@ def main(argv=None):
         if result.get("success"):
             log_print("  Status: SUCCESS")
             log_print(f"  Iterations: {result['iterations']}")
-            log_print(f"  Max displacement: {max(abs(d) for d in result['displacements']):.6e}")
+            max_u = (result["displacement_abs_max"] if "displacement_abs_max" in result
+                     else max(abs(d) for d in result["displacements"]))
+            log_print(f"  Max displacement: {max_u:.6e}")
         else:
             log_print("  Status: FAILED")
         log_print(f"{'='*60}")

@@ -74,7 +74,7 @@ def _engine_for(model: FEMModel, measured_disp, measured_dofs) -> HipEngine:
     cache = getattr(model, "_pf_engine_cache", None)
     if cache is not None and cache[0] == key and (not cache[1].n_theta or cache[1].theta.still_bound()):
         return cache[1]
-    eng = HipEngine(model, measured_disp, measured_dofs)
+    eng = HipEngine(model, measured_disp, measured_dofs, fe_mode=getattr(model, "_pf_fe_mode", None))
     model._pf_engine_cache = (key, eng)
     return eng
 

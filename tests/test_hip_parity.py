@@ -423,3 +423,40 @@ def test_net_shape_menu(width, layers, dim, wg):
     assert rel_err(gu.cpu().numpy(), ref.grad_u) < 3e-5
     ref_t = np.concatenate([g.reshape(-1) for g in ref.grad_theta])
     assert rel_err(gt.cpu().numpy(), ref_t) < 1e-4
+
+
+def test_cli_synthetic_chain_compact_output(tmp_path):
+    """`generic.py` on a generated 200k-element chain (accel.synthetic_chain), compact npz output;
+    the first increment's iterations are checked against the oracle on the same theta."""
+    import json
+    from pinn_fem_amd.cli import generic as g
+    data = {"accel": {"synthetic_chain": {"n_elements": 200_000, "h": 1e-5}, "fe_mode": "delta"},
+            "material": {"young": 1.0, "area": 1.0, "density": 1.0}, "solver_type": "pinn-gd",
+            "nn_config": {"young": {"enabled": True, "neurons_per_layer": 20, "input_dim": 3},
+                          "area": {"enabled": True, "neurons_per_layer": 15, "input_dim": 3}},
+            "pinn_config": {"max_iterations": 12, "learning_rate_u": 1e-3, "learning_rate_theta": 1e-3,
+                            "alpha_data": 100.0},
+            "solver_config": {"n_increments": 1}}
+    f = tmp_path / "chain.json"
+    f.write_text(json.dumps(data))
+    torch.manual_seed(11)
+    parsed = g.parse_problem(str(f))
+    model = parsed["model"]
+    theta = [p.detach().numpy().copy() for p in model.material.get_all_torch_params()]
+    out = g.solve_problem(parsed)
+    arrays = out.pop("_arrays")
+    assert out["iterations"] == 12 and "displacements" not in out
+    assert arrays["displacements"].shape == (400_002,) and arrays["young_at_elements_lf1.0"].shape == (200_000,)
+    md = parsed["measured_data"]
+    pb = orc.Problem(nodes=model.nodes, elements=model.elements, loads=model.loads, fixed_dofs=model.fixed_dofs,
+                     dimension=2, young=orc.NetParams(theta[0:6]), area=orc.NetParams(theta[6:12]),
+                     measured_vals=md["values"], measured_dofs=md["dofs"])
+    ref = orc.solve_gd(pb, orc.SolverConfig(max_iterations=12, learning_rate_u=1e-3, learning_rate_theta=1e-3),
+                       1.0, fe_mode="delta")
+    assert rel_err(arrays["displacements"], ref.displacements.flatten()) < 2e-5
+    assert rel_err([h["loss_total"] for h in out["history"]], [h["loss_total"] for h in ref.history]) < 1e-4
+    # and through main(): files next to the input
+    g.main(["generic.py", str(f)])
+    res = json.loads((tmp_path / "chain.res.json").read_text())
+    assert res["arrays_npz"] == "chain.res.npz" and (tmp_path / "chain.res.npz").exists()
+    assert (tmp_path / "chain.log").exists()

@@ -203,3 +203,22 @@ def test_api_pinn_gd_surface(tmp_path):
     assert r.returncode == 1
     err = json.loads(fout.read_text())
     assert err["type"] == "ValueError" and "measured_disp" in err["error"]
+
+
+def test_synthetic_chain_json(tmp_path):
+    """build-only "accel" namespace: mesh generator for large runs; reference JSONs are unaffected."""
+    from pinn_fem_amd.cli import generic as g
+    data = {"accel": {"synthetic_chain": {"n_elements": 1000, "h": 0.5, "tip_load": 2.0}, "fe_mode": "delta"},
+            "material": {"young": 1.0, "area": 1.0, "density": 1.0}, "solver_type": "pinn-gd",
+            "nn_config": {"young": {"enabled": True, "neurons_per_layer": 20, "input_dim": 3}},
+            "pinn_config": {"max_iterations": 30, "learning_rate_u": 0.01, "learning_rate_theta": 1e-3},
+            "solver_config": {"n_increments": 2}}
+    f = tmp_path / "chain.json"
+    f.write_text(json.dumps(data))
+    p = g.parse_problem(str(f))
+    m = p["model"]
+    assert m.nelm == 1000 and m.nnode == 1001 and m.loads[2000] == 2.0 and m.nodes[-1, 0] == 500.0
+    assert len(m.fixed_dofs) == 1002 and p["measured_data"]["dofs"].size == 2000
+    assert p["solver_config"].n_increments == 2 and p["solver_config"].max_iterations == 30
+    assert getattr(m, "_pf_fe_mode", 0) == 1 and p["accel"]["fe_mode"] == "delta"
+    assert "accel" in g.parse_problem(input_json("example3"))
