@@ -430,11 +430,11 @@ def test_cli_synthetic_chain_compact_output(tmp_path):
     the first increment's iterations are checked against the oracle on the same theta."""
     import json
     from pinn_fem_amd.cli import generic as g
-    data = {"accel": {"synthetic_chain": {"n_elements": 200_000, "h": 1e-5}, "fe_mode": "delta"},
+    data = {"accel": {"synthetic_chain": {"n_elements": 200_000, "h": 1.0}, "fe_mode": "delta"},
             "material": {"young": 1.0, "area": 1.0, "density": 1.0}, "solver_type": "pinn-gd",
             "nn_config": {"young": {"enabled": True, "neurons_per_layer": 20, "input_dim": 3},
                           "area": {"enabled": True, "neurons_per_layer": 15, "input_dim": 3}},
-            "pinn_config": {"max_iterations": 12, "learning_rate_u": 1e-3, "learning_rate_theta": 1e-3,
+            "pinn_config": {"max_iterations": 12, "learning_rate_u": 1e-2, "learning_rate_theta": 1e-3,
                             "alpha_data": 100.0},
             "solver_config": {"n_increments": 1}}
     f = tmp_path / "chain.json"
@@ -451,7 +451,7 @@ def test_cli_synthetic_chain_compact_output(tmp_path):
     pb = orc.Problem(nodes=model.nodes, elements=model.elements, loads=model.loads, fixed_dofs=model.fixed_dofs,
                      dimension=2, young=orc.NetParams(theta[0:6]), area=orc.NetParams(theta[6:12]),
                      measured_vals=md["values"], measured_dofs=md["dofs"])
-    ref = orc.solve_gd(pb, orc.SolverConfig(max_iterations=12, learning_rate_u=1e-3, learning_rate_theta=1e-3),
+    ref = orc.solve_gd(pb, orc.SolverConfig(max_iterations=12, learning_rate_u=1e-2, learning_rate_theta=1e-3),
                        1.0, fe_mode="delta")
     assert rel_err(arrays["displacements"], ref.displacements.flatten()) < 2e-5
     assert rel_err([h["loss_total"] for h in out["history"]], [h["loss_total"] for h in ref.history]) < 1e-4
