@@ -206,7 +206,11 @@ __global__ void k_pack_theta(pf_problem P) {
 // ---- parameter update + monitors / history / stop test / next Adam scalars ------------------------
 // mode 0: full iteration bookkeeping incl. theta stage 2 + Adam (solver.py:293-294, 304-355);
 // mode 1: losses + gradient reduction only (autograd binding).  One block of 1024 threads.
-__global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, int mode, int with_theta) {
+// ext_rd / ext_u2 (multi-GPU): globally reduced [sum r^2, sum d^2] and [sum u_free^2] to use instead of
+// this rank's block partials (which already belong to the next iteration when this runs).
+__global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, int mode, int with_theta,
+                                                   const float* __restrict__ ext_rd,
+                                                   const float* __restrict__ ext_u2) {
   pf_state* S = P.state;
   if (S->done) return;
   extern __shared__ float new_theta[];  // n_theta_active floats
@@ -219,9 +223,14 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
     b += (double)P.partials[PF_PART_D2 + i];
     if (mode == 0) c += (double)P.partials[PF_PART_U2 + i];
   }
-  const float sum_r2 = (float)pf_block_sum_d(a, dred);
-  const float sum_d2 = (float)pf_block_sum_d(b, dred);
-  const float sum_u2 = (float)pf_block_sum_d(c, dred);   // (also orders new_theta writes before reads)
+  float sum_r2 = (float)pf_block_sum_d(a, dred);
+  float sum_d2 = (float)pf_block_sum_d(b, dred);
+  float sum_u2 = (float)pf_block_sum_d(c, dred);   // (also orders new_theta writes before reads)
+  if (ext_rd) {
+    sum_r2 = ext_rd[0];
+    sum_d2 = ext_rd[1];
+    sum_u2 = ext_u2[0];
+  }
   const float loss_p = 0.5f * sum_r2;                                   // solver.py:270
   float loss_d = 0.f, loss;
   if (P.use_data) {
@@ -384,15 +393,6 @@ __global__ __launch_bounds__(1024) void k_adam_theta(pf_problem P) {
   }
 }
 
-// copy globally reduced sums into partial slot 0 so that k_finalize(nb_node = 1) consumes them
-__global__ void k_store_sums(pf_problem P, const float* __restrict__ rd, const float* __restrict__ u2) {
-  if (threadIdx.x == 0) {
-    P.partials[PF_PART_R2] = rd[0];
-    P.partials[PF_PART_D2] = rd[1];
-    P.partials[PF_PART_U2] = u2[0];
-  }
-}
-
 __global__ void k_reset(pf_problem P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < P.mesh.n_dofs) { P.m_u[i] = 0.f; P.v_u[i] = 0.f; }
@@ -547,7 +547,8 @@ int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_
     pf_set_error("too many trainable parameters for the fused finalize kernel");
     return PF_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), lds, s, *p, nb_node, mode, wt);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), lds, s, *p, nb_node, mode, wt,
+                     (const float*)nullptr, (const float*)nullptr);
   return PF_CHECK_LAUNCH();
 }
 
@@ -614,7 +615,6 @@ int pf_launch_adam_theta(const pf_problem* p, hipStream_t s) {
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, hipStream_t s) {
-  hipLaunchKernelGGL(k_store_sums, dim3(1), dim3(64), 0, s, *p, rd, u2);
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, *p, 1, 0, 0);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, *p, 0, 0, 0, rd, u2);
   return PF_CHECK_LAUNCH();
 }

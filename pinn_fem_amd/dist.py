@@ -5,10 +5,14 @@ build's answer to BASELINE.json's "shard elements across the 8 GPUs of one node"
 
 Partition: contiguous element ranges.  A node whose elements live on several ranks is SHARED; every
 sharing rank keeps a copy of its u and Adam state, and the lowest sharing rank OWNS it (counts it in
-global sums, adds its data-loss term).  Per GD iteration there are three small all-reduces:
-  (1) interface vector of partial f_int          -> every sharing rank has the full f_int / residual
+global sums, adds its data-loss term).  Per GD iteration there are TWO small all-reduces, the floor
+for this partition (one exchange before the residual, one after the backward):
+  (1) [sum u_free^2 of the PREVIOUS iteration | interface vector of partial f_int]
   (2) [interface grad_u | grad_theta | sum r^2, sum d^2]
-  (3) sum u_free^2                                (monitor only)
+The u-norm is a monitor only, so it rides on the next iteration's first collective and the
+bookkeeping kernel of iteration t (history row, stop test, next Adam scalars) runs right after that
+collective, before anything of iteration t+1 that could change state; a chunk ends with one flush
+collective.
 Everything else (u, f_int, Adam-u state, residual) stays sharded; theta and its Adam state are
 replicated and stay bit-identical because every rank applies the same reduced gradient.
 For a 1-D chain cut into G shards the interface has 2(G-1) dofs, so the traffic is ~4 kB per
@@ -133,7 +137,9 @@ def shard_host_plan(shard: Shard, nodes, loads, fixed_dofs, measured_disp, measu
 # iteration driver (backend-agnostic)
 # ---------------------------------------------------------------------------------------------------
 class ShardBackend:
-    """What the driver needs from one rank's local problem.  All tensors live on `device`."""
+    """What the driver needs from one rank's local problem.  All tensors live on `device`.
+    Buffers: buf1 = [3 floats: -, -, sum u_free^2 | interface f_int (n_iface)],
+             buf2 = [interface grad_u (n_iface) | grad_theta (n_theta_active) | sum r^2, sum d^2, -]."""
     device: torch.device
     n_iface: int
     n_theta_active: int
@@ -142,7 +148,7 @@ class ShardBackend:
     def pack_f(self, iface: torch.Tensor): ...            # iface[slot] = partial f_int (else 0)
     def fix_residual(self, iface: torch.Tensor): ...      # full f_int on shared dofs -> residual
     def backward(self, buf2: torch.Tensor): ...           # -> [iface grad_u | grad_theta | r2, d2, -]
-    def update(self, buf2: torch.Tensor, u2: torch.Tensor): ...  # Adam(u), Adam(theta); u2[2]=local sum
+    def update(self, buf2: torch.Tensor, sums3: torch.Tensor): ...  # Adam(u), Adam(theta); sums3[2]=local sum u^2
     def finalize(self, r2d2: torch.Tensor, u2: torch.Tensor): ...
 
 
@@ -159,39 +165,43 @@ def _all_reduce(t: torch.Tensor, group=None):
 
 
 def run_iterations(backend: ShardBackend, n_iter: int, group=None,
-                   bufs: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None):
-    """n_iter GD iterations with the three collectives of the module docstring."""
+                   bufs: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """n_iter GD iterations with the two collectives per iteration of the module docstring (+ one
+    flush at the end, so the device state is final when this returns)."""
     if bufs is None:
         bufs = make_buffers(backend)
-    if1, buf2, u2 = bufs
-    nt = backend.n_theta_active
     eng = getattr(backend, "eng", None)
     ctx = eng.on_stream() if eng is not None else contextlib.nullcontext()
     with ctx:   # kernels and collectives on one stream (the engine's)
-        _run_iterations(backend, n_iter, group, if1, buf2, u2, nt)
+        _run_iterations(backend, n_iter, group, bufs[0], bufs[1])
     return bufs
 
 
-def _run_iterations(backend, n_iter, group, if1, buf2, u2, nt):
+def _run_iterations(backend, n_iter, group, buf1, buf2):
+    ni, nt = backend.n_iface, backend.n_theta_active
+    r2d2 = buf2[ni + nt:ni + nt + 2]
+    pending = False
     for _ in range(n_iter):
         backend.forward_residual()
-        backend.pack_f(if1)
-        _all_reduce(if1, group)
-        backend.fix_residual(if1)
+        backend.pack_f(buf1[3:])
+        _all_reduce(buf1, group)                 # (1) + the previous iteration's sum u^2 in buf1[2]
+        if pending:
+            backend.finalize(r2d2, buf1[2:3])    # bookkeeping of the previous iteration
+        backend.fix_residual(buf1[3:])
         backend.backward(buf2)
-        _all_reduce(buf2, group)
-        backend.update(buf2, u2)
-        _all_reduce(u2, group)
-        backend.finalize(buf2[backend.n_iface + nt:backend.n_iface + nt + 2], u2[2:3])
+        _all_reduce(buf2, group)                 # (2)
+        backend.update(buf2, buf1[:3])
+        pending = True
+    if pending:
+        _all_reduce(buf1[:3], group)             # flush: the last iteration's sum u^2
+        backend.finalize(r2d2, buf1[2:3])
 
 
 def make_buffers(backend: ShardBackend):
     dev = backend.device
     f32 = dict(dtype=torch.float32, device=dev)
-    # buf2 = [interface grad_u | grad_theta | sum r^2, sum d^2, (unused)] ; u2 = [-, -, sum u_free^2]
-    return (torch.zeros(max(backend.n_iface, 1), **f32),
-            torch.zeros(backend.n_iface + backend.n_theta_active + 3, **f32),
-            torch.zeros(3, **f32))
+    return (torch.zeros(3 + backend.n_iface, **f32),
+            torch.zeros(backend.n_iface + backend.n_theta_active + 3, **f32))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -247,9 +257,9 @@ class HipShardBackend(ShardBackend):
         _capi.check(e.lib.pf_shard_phase2(e._ref(), self._if1_ptr, buf2.data_ptr(), e._stream()),
                     "pf_shard_phase2")
 
-    def update(self, buf2, u2):
+    def update(self, buf2, sums3):
         e = self.eng
-        _capi.check(e.lib.pf_shard_phase3(e._ref(), buf2.data_ptr(), u2.data_ptr(), e._stream()),
+        _capi.check(e.lib.pf_shard_phase3(e._ref(), buf2.data_ptr(), sums3.data_ptr(), e._stream()),
                     "pf_shard_phase3")
 
     def finalize(self, r2d2, u2):

@@ -93,7 +93,7 @@ class OracleShardBackend(ShardBackend):
             off += g.size
         b[self.n_iface + self.n_theta_active:self.n_iface + self.n_theta_active + 2] = (self.r2, self.d2)
 
-    def update(self, buf2, u2):
+    def update(self, buf2, sums3):
         b = buf2.numpy()
         self.grad_u[self.shard.shared_dofs] = b[self.shard.shared_slot]
         self.opt_u.update([self.u], [self.grad_u])
@@ -107,7 +107,7 @@ class OracleShardBackend(ShardBackend):
         if self.theta:
             self.opt_t.update(self.theta, grads)
         self.u[~self.free] = 0
-        u2.numpy()[2] = np.sum((self.u * self.u)[self.free & self.owned], dtype=f32)
+        sums3.numpy()[2] = np.sum((self.u * self.u)[self.free & self.owned], dtype=f32)
 
     def finalize(self, r2d2, u2):
         if self.done:
