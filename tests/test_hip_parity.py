@@ -460,3 +460,95 @@ def test_cli_synthetic_chain_compact_output(tmp_path):
     res = json.loads((tmp_path / "chain.res.json").read_text())
     assert res["arrays_npz"] == "chain.res.npz" and (tmp_path / "chain.res.npz").exists()
     assert (tmp_path / "chain.log").exists()
+
+
+def _random_truss(n_nodes, rng, hub_degree=0):
+    """Random planar truss: nodes on a jittered grid, elements to nearest neighbours (+ an optional
+    hub node connected to `hub_degree` nodes: skewed node degree)."""
+    side = int(np.ceil(np.sqrt(n_nodes)))
+    ij = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2)[:n_nodes]
+    nodes = ij + rng.uniform(-0.3, 0.3, ij.shape)
+    el = set()
+    idx = {tuple(p): k for k, p in enumerate(ij)}
+    for k, (i, j) in enumerate(ij):
+        for di, dj in ((1, 0), (0, 1), (1, 1), (1, -1)):
+            q = idx.get((i + di, j + dj))
+            if q is not None:
+                el.add((k, q))
+    el = sorted(el)
+    if hub_degree:
+        far = rng.choice(np.arange(1, n_nodes), size=hub_degree, replace=False)
+        el += [(0, int(q)) for q in far if (0, int(q)) not in el]
+    el = np.array(el)
+    rng.shuffle(el)                                   # element order != node order
+    flip = rng.random(len(el)) < 0.5                  # random element orientation
+    el[flip] = el[flip][:, ::-1]
+    return nodes, el
+
+
+@pytest.mark.parametrize("n_nodes,hub", [(400, 0), (2500, 300)])
+def test_irregular_truss_vs_oracle(n_nodes, hub):
+    """General connectivity: shuffled element order, random orientation, node degree up to 300."""
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.properties import NNProperty
+    from pinn_fem_amd.nets import SimpleNN
+    rng = np.random.default_rng(n_nodes)
+    nodes, elements = _random_truss(n_nodes, rng, hub)
+    ndof = 2 * n_nodes
+    loads = rng.normal(size=ndof) * 0.05
+    fixed = np.unique(rng.choice(ndof, size=ndof // 20, replace=False))
+    u = (rng.normal(size=ndof) * 0.01).astype(np.float32)
+    u[fixed] = 0
+    md = rng.choice(ndof, size=ndof // 3, replace=False)
+    mv = rng.normal(size=md.size) * 0.01
+    torch.manual_seed(5)
+    ne, na = SimpleNN(2, 20, 3), SimpleNN(2, 15, 3)
+    th = [p.detach().numpy().copy() for p in list(ne.parameters()) + list(na.parameters())]
+    model = FEMModel(nodes, elements, Material(NNProperty(ne, 3, True, 2.0), NNProperty(na, 3, True, 0.3)), loads, fixed)
+    pb = orc.Problem(nodes=nodes, elements=elements, loads=loads, fixed_dofs=fixed, dimension=2,
+                     young=orc.NetParams(th[0:6], 2.0), area=orc.NetParams(th[6:12], 0.3),
+                     measured_vals=mv, measured_dofs=md)
+    ref = orc.loss_and_grads(pb, orc.element_geometry(pb), u, 0.8, 1.0, 100.0)
+    eng = _engine(model, mv, md, 2)
+    losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.8, 1.0, 100.0)
+    f_int = eng.internal_force(torch.from_numpy(u), 0.8).cpu().numpy()
+    assert rel_err(f_int, ref.f_int) < 5e-6
+    assert abs(losses["loss_total"] - ref.loss_total) < 2e-5 * abs(ref.loss_total)
+    assert rel_err(gu.cpu().numpy(), ref.grad_u) < 2e-5
+    assert rel_err(gt.cpu().numpy(), np.concatenate([g.reshape(-1) for g in ref.grad_theta])) < 1e-4
+    assert rel_err(eng.diag_k(0.8).cpu().numpy(), orc.diag_stiffness(pb, orc.element_geometry(pb), 0.8)) < 2e-6
+    # 15 GD iterations from this state: same trajectory as the oracle
+    from pinn_fem_amd.fem.solver import SolverConfig, solve_gd
+    cfg = SolverConfig(max_iterations=15, learning_rate_u=1e-3, learning_rate_theta=1e-3, tolerance=1e-14)
+    res = solve_gd(model, cfg, mv, md, target_load_factor=0.8, u_initial=torch.from_numpy(u))
+    r2 = orc.solve_gd(pb, orc.SolverConfig(max_iterations=15, learning_rate_u=1e-3, learning_rate_theta=1e-3,
+                                           tolerance=1e-14), 0.8, u_initial=u)
+    assert rel_err(res.displacements.flatten(), r2.displacements.flatten()) < 2e-5
+    assert rel_err([h["loss_total"] for h in res.history], [h["loss_total"] for h in r2.history]) < 1e-4
+
+
+def test_error_behaviour_matches_reference_semantics():
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.properties import NNProperty
+    from pinn_fem_amd.fem.solver import SolverConfig, solve, solve_gd, solve_hybrid
+    from pinn_fem_amd.nets import SimpleNN
+    nodes = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 0.0]])
+    with pytest.raises(ValueError, match="zero initial length"):       # nn_assembly.py:66-67
+        solve_gd(FEMModel(nodes, np.array([[1, 2]]), Material(1.0, 1.0), np.zeros(6), np.array([0])))
+    with pytest.raises(ValueError, match="loads size"):                # model.py:78-79
+        FEMModel(nodes[:2], np.array([[0, 1]]), Material(1.0, 1.0), np.zeros(3), np.array([0]))
+    # NN with input_dim != dimension+1: the reference raises a torch shape error (properties.py:150)
+    bad = FEMModel(nodes[:2], np.array([[0, 1]]), Material(NNProperty(SimpleNN(2, 8, 2), 2), 1.0), np.zeros(4),
+                   np.array([0, 1, 3]))
+    with pytest.raises(RuntimeError, match="cannot be multiplied"):
+        solve_gd(bad, SolverConfig(max_iterations=2))
+    ok = FEMModel(nodes[:2], np.array([[0, 1]]), Material(1.0, 1.0), np.array([0, 0, 1.0, 0]), np.array([0, 1, 3]))
+    with pytest.raises(NotImplementedError):                           # scalar hybrid -> solve_nr (out of scope)
+        solve_hybrid(ok, SolverConfig(max_iterations=20))
+    with pytest.raises(NotImplementedError):                           # auto + no NN + no data -> nr
+        solve(ok, SolverConfig(max_iterations=20))
+    with pytest.raises(ValueError, match="Unknown solver method"):
+        solve(ok, SolverConfig(method="bogus"))
+    r = solve(ok, SolverConfig(method="gd", max_iterations=400, learning_rate_u=0.01, n_increments=2))
+    assert r.converged and abs(r.displacements[1, 0] - 1.0) < 5e-3 and r.nn_parameters is None
+    assert set(r.history[0]) == {"iteration", "loss_total", "loss_physics", "loss_data", "u_norm", "residual_norm"}
