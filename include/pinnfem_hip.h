@@ -246,6 +246,11 @@ int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* s
 int pf_shard_phase1(const pf_problem* p, float* fbuf, float* iface1, void* stream);
 int pf_shard_phase2(const pf_problem* p, const float* iface1, float* buf2, void* stream);
 int pf_shard_phase3(const pf_problem* p, const float* buf2, float* u2, void* stream);
+/* hipGraph form of the three phases (same contract as pf_graph_create: the record and the buffer
+ * pointers are baked in).  graphs_out receives 3 opaque handles (phase 1, 2, 3) for pf_graph_launch /
+ * pf_graph_destroy. */
+int pf_shard_graphs_create(const pf_problem* p, float* fbuf, float* iface1, float* buf2, float* sums3,
+                           void* stream, void** graphs_out);
 
 /* ---- extensions (off the default path) ------------------------------------------------ */
 /* generic Adam (torch.optim.Adam single-tensor arithmetic) on a flat vector */

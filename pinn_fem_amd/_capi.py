@@ -116,6 +116,8 @@ SYMBOLS = {
     "pf_shard_phase1": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_shard_phase2": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_shard_phase3": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_shard_graphs_create": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.POINTER(C.c_void_p)]),
     "pf_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pf_diag_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),

@@ -544,6 +544,46 @@ int pf_shard_phase3(const pf_problem* p, const float* buf2, float* u2, void* str
   return PF_OK;
 }
 
+}  // extern "C"
+template <class F>
+static int capture_graph(hipStream_t s, F&& body, void** out) {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
+    return fail(PF_ERR_HIP, "hipStreamBeginCapture failed");
+  const int rc = body();
+  const hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != PF_OK) {
+    if (graph) hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess || !graph) return fail(PF_ERR_HIP, "hipStreamEndCapture failed");
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    hipGraphDestroy(graph);
+    return fail(PF_ERR_HIP, "hipGraphInstantiate failed");
+  }
+  hipGraphDestroy(graph);
+  *out = (void*)exec;
+  return PF_OK;
+}
+extern "C" {
+
+int pf_shard_graphs_create(const pf_problem* p, float* fbuf, float* iface1, float* buf2, float* sums3,
+                           void* stream, void** graphs_out) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!fbuf || !iface1 || !buf2 || !sums3 || !graphs_out) return fail(PF_ERR_ARG, "pf_shard_graphs_create: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  graphs_out[0] = graphs_out[1] = graphs_out[2] = nullptr;
+  rc = capture_graph(s, [&]() { return pf_shard_phase1(p, fbuf, iface1, stream); }, &graphs_out[0]);
+  if (rc == PF_OK) rc = capture_graph(s, [&]() { return pf_shard_phase2(p, iface1, buf2, stream); }, &graphs_out[1]);
+  if (rc == PF_OK) rc = capture_graph(s, [&]() { return pf_shard_phase3(p, buf2, sums3, stream); }, &graphs_out[2]);
+  if (rc != PF_OK)
+    for (int i = 0; i < 3; ++i)
+      if (graphs_out[i]) { hipGraphExecDestroy((hipGraphExec_t)graphs_out[i]); graphs_out[i] = nullptr; }
+  return rc;
+}
+
 int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,
             double beta1, double beta2, double eps, void* stream) {
   if (!param || !grad || !m || !v || n < 0 || step < 1) return fail(PF_ERR_ARG, "pf_adam: bad argument");

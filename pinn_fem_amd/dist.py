@@ -24,6 +24,7 @@ HipShardBackend (HIP kernels).  Tests drive the same driver with a CPU reference
 from __future__ import annotations
 
 import contextlib
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -169,7 +170,7 @@ def run_iterations(backend: ShardBackend, n_iter: int, group=None,
     """n_iter GD iterations with the two collectives per iteration of the module docstring (+ one
     flush at the end, so the device state is final when this returns)."""
     if bufs is None:
-        bufs = make_buffers(backend)
+        bufs = getattr(backend, "bufs", None) or make_buffers(backend)
     eng = getattr(backend, "eng", None)
     ctx = eng.on_stream() if eng is not None else contextlib.nullcontext()
     with ctx:   # kernels and collectives on one stream (the engine's)
@@ -222,13 +223,38 @@ class HipShardBackend(ShardBackend):
         self.n_iface = shard.n_iface
         self.n_theta_active = self.eng.n_theta_active
         self.fbuf = torch.zeros(host_plan.n_dofs, dtype=torch.float32, device=self.device)
-        self._buf2_ptr = None
+        self.bufs = make_buffers(self)           # (buf1, buf2): fixed addresses, baked into the graphs
+        self._graphs = None
+        self.use_graphs = os.environ.get("PINNFEM_GRAPH", "1") != "0"
 
     # -- solve_gd-level control ---------------------------------------------------------------------
     def begin(self, u_initial_local, lam, config, want_history=True):
+        self._drop_graphs()
         self.eng.begin(u_initial_local, lam, config, want_history=want_history)
+        # gradients land where the collectives read them: grad_theta is reduced straight into buf2
         self.eng.P.grad_u = self.eng.grad_u.data_ptr()
-        self._buf2_ptr = None   # begin() re-pointed grad_theta at the engine's own buffer
+        self.eng.P.grad_theta = self.bufs[1].data_ptr() + 4 * self.n_iface
+
+    def _drop_graphs(self):
+        if self._graphs:
+            for g in self._graphs:
+                self.eng.lib.pf_graph_destroy(g)
+        self._graphs = None
+
+    def _phase(self, k, eager):
+        """Phase k (0..2) of the iteration: replay its hipGraph (captured on first use) or launch eagerly."""
+        e = self.eng
+        if not self.use_graphs:
+            return eager()
+        if self._graphs is None:
+            import ctypes as C
+            arr = (C.c_void_p * 3)()
+            buf1, buf2 = self.bufs
+            _capi.check(e.lib.pf_shard_graphs_create(e._ref(), self.fbuf.data_ptr(), buf1.data_ptr() + 12,
+                                                     buf2.data_ptr(), buf1.data_ptr(), e._stream(), arr),
+                        "pf_shard_graphs_create")
+            self._graphs = [C.c_void_p(arr[i]) for i in range(3)]
+        _capi.check(e.lib.pf_graph_launch(self._graphs[k], e._stream()), "pf_graph_launch")
 
     def state(self):
         return self.eng.state()
@@ -236,31 +262,38 @@ class HipShardBackend(ShardBackend):
     def history(self, n):
         return self.eng.history(n)
 
-    # -- ShardBackend: one C call per phase (pf_shard_phase1..3, pf_finalize_from) ------------------------
+    # -- ShardBackend: one C call (or one graph replay) per phase, pf_finalize_from for the bookkeeping ----
+    def _check_bufs(self, *tensors):
+        buf1, buf2 = self.bufs
+        lo1, hi1 = buf1.data_ptr(), buf1.data_ptr() + 4 * buf1.numel()
+        lo2, hi2 = buf2.data_ptr(), buf2.data_ptr() + 4 * buf2.numel()
+        for t in tensors:
+            p = t.data_ptr()
+            if not (lo1 <= p < hi1 or lo2 <= p < hi2):
+                raise ValueError("HipShardBackend works on its own collective buffers (backend.bufs)")
+
     def forward_residual(self):
         pass                                   # done together with the interface pack in pack_f()
 
     def pack_f(self, iface):
         e = self.eng
-        _capi.check(e.lib.pf_shard_phase1(e._ref(), self.fbuf.data_ptr(), iface.data_ptr(), e._stream()),
-                    "pf_shard_phase1")
+        self._check_bufs(iface)
+        self._phase(0, lambda: _capi.check(
+            e.lib.pf_shard_phase1(e._ref(), self.fbuf.data_ptr(), iface.data_ptr(), e._stream()), "pf_shard_phase1"))
 
     def fix_residual(self, iface):
         self._if1_ptr = iface.data_ptr()       # consumed at the start of phase 2
 
     def backward(self, buf2):
         e = self.eng
-        if self._buf2_ptr != buf2.data_ptr():
-            # gradients of theta are reduced straight into the collective buffer
-            self._buf2_ptr = buf2.data_ptr()
-            e.P.grad_theta = buf2.data_ptr() + 4 * self.n_iface
-        _capi.check(e.lib.pf_shard_phase2(e._ref(), self._if1_ptr, buf2.data_ptr(), e._stream()),
-                    "pf_shard_phase2")
+        self._check_bufs(buf2)
+        self._phase(1, lambda: _capi.check(
+            e.lib.pf_shard_phase2(e._ref(), self._if1_ptr, buf2.data_ptr(), e._stream()), "pf_shard_phase2"))
 
     def update(self, buf2, sums3):
         e = self.eng
-        _capi.check(e.lib.pf_shard_phase3(e._ref(), buf2.data_ptr(), sums3.data_ptr(), e._stream()),
-                    "pf_shard_phase3")
+        self._phase(2, lambda: _capi.check(
+            e.lib.pf_shard_phase3(e._ref(), buf2.data_ptr(), sums3.data_ptr(), e._stream()), "pf_shard_phase3"))
 
     def finalize(self, r2d2, u2):
         e = self.eng
@@ -370,7 +403,7 @@ class ShardedChainEngine:
         model = FEMModel(nodes=nodes_l, elements=el, material=Material(*props), loads=loads,
                          fixed_dofs=fixed, dimension=2)
         self.backend = HipShardBackend(model, hp, shard, True, device=device)
-        self.bufs = make_buffers(self.backend)
+        self.bufs = self.backend.bufs
 
     def begin(self, u0, lam, config):
         self.backend.begin(u0, lam, config, want_history=False)

@@ -258,7 +258,7 @@ def _solve_gd_sharded(model, config, measured_disp, measured_dofs, lam, u_initia
         ug = u_initial.detach().cpu().numpy() if isinstance(u_initial, torch.Tensor) else np.asarray(u_initial)
         u0 = torch.from_numpy(np.ascontiguousarray(ug.reshape(-1)[be.dofs_global], dtype=np.float32))
     be.begin(u0, lam, config)
-    bufs = pfd.make_buffers(be)
+    bufs = be.bufs
     n_done, st = 0, None
     while n_done < config.max_iterations:
         chunk = min(CHECK_EVERY, config.max_iterations - n_done)
