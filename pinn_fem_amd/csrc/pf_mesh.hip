@@ -119,6 +119,12 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P) {
       }
       if (P.grad_u) P.grad_u[dof] = gu;
       if (FUSE_ADAM) {
+        if (fl & PF_DOF_FIXED) {
+          // solver.py:297-298: u[fixed] = 0 after the step.  The Adam moments of a fixed dof only ever
+          // feed that dof's own (discarded) update, so they are dead state: not loaded, not stored.
+          if (uo != 0.f) P.u[dof] = 0.f;
+          continue;
+        }
         // torch.optim.Adam single-tensor arithmetic (torch/optim/adam.py)
         float m = P.m_u[dof], v = P.v_u[dof];
         m = m + b1w * (gu - m);                       // lerp_
@@ -126,8 +132,7 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P) {
         v = v + (b2w * gu) * gu;                      // addcmul_
         const float denom = sqrtf(v) / bc2s + eps;
         uo = uo + (-step_size) * (m / denom);         // addcdiv_
-        if (fl & PF_DOF_FIXED) uo = 0.f;              // solver.py:297-298 (moments keep evolving)
-        else if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
+        if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
         P.m_u[dof] = m;
         P.v_u[dof] = v;
         P.u[dof] = uo;
@@ -356,15 +361,19 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_adam_u(pf_problem P) {
   float sum_u2 = 0.f;
   for (int dof = blockIdx.x * blockDim.x + threadIdx.x; dof < M.n_dofs; dof += gridDim.x * blockDim.x) {
     const unsigned fl = M.dof_flags[dof];
+    float uo = P.u[dof];
+    if (fl & PF_DOF_FIXED) {               // dead Adam state of fixed dofs: see k_node_gradu
+      if (uo != 0.f) P.u[dof] = 0.f;
+      continue;
+    }
     const float gu = P.grad_u[dof];
-    float m = P.m_u[dof], v = P.v_u[dof], uo = P.u[dof];
+    float m = P.m_u[dof], v = P.v_u[dof];
     m = m + b1w * (gu - m);
     v = v * b2;
     v = v + (b2w * gu) * gu;
     const float denom = sqrtf(v) / bc2s + eps;
     uo = uo + (-step_size) * (m / denom);
-    if (fl & PF_DOF_FIXED) uo = 0.f;
-    else if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
+    if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
     P.m_u[dof] = m;
     P.v_u[dof] = v;
     P.u[dof] = uo;
