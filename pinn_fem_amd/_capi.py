@@ -141,9 +141,17 @@ def load():
     # SAME HIP runtime instance (two runtimes in one process see no device)
     import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
-        raise PinnFemHipError(
-            f"{LIB_PATH} not found: the HIP library is not built. Run `python -m pinn_fem_amd.build` "
-            "(needs hipcc). pinn_fem_amd has no CPU fallback.")
+        # not a fallback: build the HIP library in-tree when a fresh checkout has none yet
+        from . import build as _build
+        if not os.path.exists(_build.HIPCC):
+            raise PinnFemHipError(
+                f"{LIB_PATH} not found and hipcc ({_build.HIPCC}) is not available: the HIP library "
+                "cannot be built. Run `python -m pinn_fem_amd.build` on a ROCm machine. "
+                "pinn_fem_amd has no CPU fallback.")
+        try:
+            _build.build(verbose=False)
+        except Exception as e:
+            raise PinnFemHipError(f"building {LIB_PATH} failed: {e}. pinn_fem_amd has no CPU fallback.") from e
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
