@@ -113,7 +113,7 @@ typedef struct pf_problem {
   int32_t n_theta_active;  /* leading parameters that receive gradients (young+area nets) */
   const int32_t* tensor_off; /* dev [n_tensors+1] parameter-tensor boundaries for theta_norm */
   int32_t n_tensors;
-  int32_t wg_mode;         /* PF_WG_* */
+  int32_t wg_mode;         /* PF_WG_* : which MLP engine runs the net kernels */
   /* scalars of SolverConfig (solver.py:35-62) */
   float lam;               /* load factor of this increment */
   float alpha_physics, alpha_data;
@@ -122,7 +122,7 @@ typedef struct pf_problem {
   double beta1, beta2, eps;
   int32_t use_data;        /* has_measurements && alpha_data>0 (solver.py:273) */
   int32_t max_iter;
-  /* workspaces, all dev, sizes from pf_workspace_sizes() */
+  /* workspaces, all dev; sizes: theta_pad pf_net_pad_count() per net, partials pf_partials_count() */
   float* theta_pad;        /* padded parameter image the net kernels read */
   float* prop_e;           /* [n_elems] young per element */
   float* prop_a;           /* [n_elems] area per element */
