@@ -337,12 +337,44 @@ def solve_problem(parsed_data):
     return output
 
 
+def _init_distributed():
+    """`python -m torch.distributed.run --nproc-per-node N generic.py problem.json`: one process per GPU,
+    elements sharded over the ranks (pinn_fem_amd/dist.py); every rank computes the same result, rank 0
+    writes the files.  PINNFEM_DIST_BACKEND=gloo + PINNFEM_ONE_GPU=1 rehearses this on a single GPU."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    import torch.distributed as dist
+    one_gpu = os.environ.get("PINNFEM_ONE_GPU", "0") == "1"
+    local = 0 if one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if not dist.is_initialized():
+        backend = os.environ.get("PINNFEM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return dist.get_rank(), world
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     if len(argv) < 2:
         print("Usage: python generic.py problem.json [output.json]")
         sys.exit(1)
     problem_file = argv[1]
+    rank, world = _init_distributed()
+    if rank != 0:
+        # non-zero ranks take part in the solve only: no log file, no result files
+        try:
+            solve_problem(parse_problem(problem_file))
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            sys.exit(1)
+        return
     log_file = setup_logging(problem_file)
     if len(argv) > 2:
         output_file = argv[2]

@@ -559,3 +559,31 @@ def test_error_behaviour_matches_reference_semantics():
     r = solve(ok, SolverConfig(method="gd", max_iterations=400, learning_rate_u=0.01, n_increments=2))
     assert r.converged and abs(r.displacements[1, 0] - 1.0) < 5e-3 and r.nn_parameters is None
     assert set(r.history[0]) == {"iteration", "loss_total", "loss_physics", "loss_data", "u_norm", "residual_norm"}
+
+
+def test_cli_under_torchrun_two_ranks_one_gpu(tmp_path):
+    """`torchrun --nproc-per-node 2 generic.py example3-P.json` (rehearsed on one GPU with gloo): the
+    sharded run writes the same result schema; displacements match the single-process run."""
+    import json
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from helpers import ROOT, input_json
+    dst = tmp_path / "example3-P.json"
+    shutil.copy(input_json("example3-P"), dst)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PINNFEM_QUIET="1", PINNFEM_DIST_BACKEND="gloo",
+               PINNFEM_ONE_GPU="1")
+    # same seed on both ranks and in the single-process run: identical initial theta
+    runner = tmp_path / "run.py"
+    runner.write_text("import sys, torch\\nsys.path.insert(0, %r)\\ntorch.manual_seed(0)\\n"
+                      "from pinn_fem_amd.cli.generic import main\\nmain(['generic.py'] + sys.argv[1:])\\n" % ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29671", str(runner), str(dst)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    sharded = json.loads((tmp_path / "example3-P.res.json").read_text())
+    run = load_run("example3-P")
+    assert sharded["converged"] == run["result"]["converged"]
+    assert rel_err(sharded["displacements"], run["result"]["displacements"]) < 1e-5
+    assert set(sharded) == set(run["result"])
