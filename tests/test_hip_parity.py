@@ -576,8 +576,8 @@ def test_cli_under_torchrun_two_ranks_one_gpu(tmp_path):
                PINNFEM_ONE_GPU="1")
     # same seed on both ranks and in the single-process run: identical initial theta
     runner = tmp_path / "run.py"
-    runner.write_text("import sys, torch\\nsys.path.insert(0, %r)\\ntorch.manual_seed(0)\\n"
-                      "from pinn_fem_amd.cli.generic import main\\nmain(['generic.py'] + sys.argv[1:])\\n" % ROOT)
+    runner.write_text("import sys, torch\nsys.path.insert(0, %r)\ntorch.manual_seed(0)\n"
+                      "from pinn_fem_amd.cli.generic import main\nmain(['generic.py'] + sys.argv[1:])\n" % ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
            "--master-addr", "127.0.0.1", "--master-port", "29671", str(runner), str(dst)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
