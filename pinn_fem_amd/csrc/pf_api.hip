@@ -308,30 +308,71 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
   return PF_OK;
 }
 
-// One iteration with the parameter-gradient tail on a side stream (only meaningful while capturing a
-// graph): [theta stage 1, stage 2 + Adam(theta)] run beside [node_gradu + Adam(u)]; both join before
-// the monitors.  Neither branch reads what the other writes.
-static int enqueue_iteration_forked(const pf_problem* p, hipStream_t s, hipStream_t side, hipEvent_t e_fork,
-                                    hipEvent_t e_join) {
+// Iterations as a dependency graph instead of a chain (only meaningful while capturing a hipGraph).
+// What each kernel of iteration t really waits for:
+//   forward E, A        theta_pad(t)  [stage 2 of t-1];  nothing reads prop_e/prop_a any more  [gradu of t-1]
+//   node_residual       forwards, u(t) [gradu of t-1], the block partials are free           [finalize of t-1]
+//   backward #1 (+gea)  g_f; it is the last reader of u(t)
+//   gradu + Adam(u)     g_f, the properties, backward #1 done; the Adam scalars                [finalize of t-1]
+//   backward #2, theta stage 1, stage 2 + Adam(theta)   in this order after backward #1
+//   finalize            stage 2 and gradu of t
+// so gradu (HBM bound) runs on branch A beside backward #2 and the theta reduction (compute bound), and
+// finalize runs on branch B beside the next iteration's forward kernels.  The stop flag is read by every
+// kernel at its start; a kernel of t+1 that misses a stop raised by finalize(t) only rewrites scratch
+// (properties, g_f, partial sums): everything that changes solver state (both Adam kernels, finalize)
+// is ordered behind finalize(t) and returns at once, so the final state is the reference's `break`.
+struct pf_capture {
+  hipStream_t s, a, b;
+  hipEvent_t* ev;   // 4 per iteration: u readers done | gradu done | theta done | finalize done
+};
+
+static int cap_edge(hipEvent_t e, hipStream_t from, hipStream_t to) {
+  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess)
+    return fail(PF_ERR_HIP, "graph edge failed");
+  return PF_OK;
+}
+
+static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_capture& c) {
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
-  if (!any_net) return enqueue_iteration(p, 1, 0, s, nullptr);
+  hipStream_t s = c.s;
+  if (!any_net) {
+    for (int i = 0; i < iters; ++i) {
+      int rc = enqueue_iteration(p, 1, 0, s, nullptr);
+      if (rc != PF_OK) return rc;
+    }
+    return PF_OK;
+  }
   const bool fuse_gea = p->wg_mode == PF_WG_MFMA44;
   const int first = p->net[0].enabled ? 0 : 1;
-  for (int k = 0; k < 2; ++k)
-    if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
-  PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
-  if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
-  for (int k = 0; k < 2; ++k)
-    if (p->net[k].enabled)
+  for (int i = 0; i < iters; ++i) {
+    hipEvent_t* e = c.ev + 4 * i;
+    hipEvent_t* ep = c.ev + 4 * (i - 1);
+    // gradu(i-1) still reads the properties the forwards overwrite, and writes the u the residual reads
+    if (i > 0 && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    for (int k = 0; k < 2; ++k)
+      if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+    // finalize(i-1) reads the block partials node_residual rewrites, and writes the Adam scalars
+    if (i > 0 && hipStreamWaitEvent(s, ep[3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
+    if (!fuse_gea) {
+      PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+      if (cap_edge(e[0], s, c.a) != PF_OK) return PF_ERR_HIP;
+    }
+    for (int k = 0; k < 2; ++k) {
+      if (!p->net[k].enabled) continue;
       PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
-  if (hipEventRecord(e_fork, s) != hipSuccess || hipStreamWaitEvent(side, e_fork, 0) != hipSuccess)
-    return fail(PF_ERR_HIP, "graph fork failed");
-  PF_TRY(pf_launch_theta_stage1(p, side), "theta_stage1");
-  PF_TRY(pf_launch_theta_stage2(p, 1, side), "theta_stage2");
-  PF_TRY(pf_launch_node_gradu(p, 1, s), "node_gradu");
-  if (hipEventRecord(e_join, side) != hipSuccess || hipStreamWaitEvent(s, e_join, 0) != hipSuccess)
-    return fail(PF_ERR_HIP, "graph join failed");
-  PF_TRY(pf_launch_finalize(p, 0, 0, s), "finalize");
+      if (fuse_gea && k == first && cap_edge(e[0], s, c.a) != PF_OK) return PF_ERR_HIP;
+    }
+    PF_TRY(pf_launch_node_gradu(p, 1, c.a), "node_gradu");
+    if (cap_edge(e[1], c.a, c.b) != PF_OK) return PF_ERR_HIP;
+    PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
+    PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
+    if (cap_edge(e[2], s, c.b) != PF_OK) return PF_ERR_HIP;
+    PF_TRY(pf_launch_finalize(p, 0, 0, c.b), "finalize");
+    if (hipEventRecord(e[3], c.b) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+  }
+  // join: finalize of the last iteration is behind everything else
+  if (hipStreamWaitEvent(s, c.ev[4 * (iters - 1) + 3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
   return PF_OK;
 }
 
@@ -342,18 +383,20 @@ int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void
   hipStream_t s = (hipStream_t)stream;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  hipStream_t side = nullptr;
-  const int nev = 2 * iters_per_graph;
+  hipStream_t side[2] = {nullptr, nullptr};
+  const int nev = 4 * iters_per_graph;
   hipEvent_t* ev = new hipEvent_t[nev];
   int made = 0;
-  bool ok = hipStreamCreateWithFlags(&side, hipStreamNonBlocking) == hipSuccess;
+  bool ok = hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&side[1], hipStreamNonBlocking) == hipSuccess;
   for (; ok && made < nev; ++made)
     if (hipEventCreateWithFlags(&ev[made], hipEventDisableTiming) != hipSuccess) break;
   ok = ok && made == nev;
   auto cleanup = [&]() {
     for (int i = 0; i < made; ++i) hipEventDestroy(ev[i]);
     delete[] ev;
-    if (side) hipStreamDestroy(side);
+    for (int k = 0; k < 2; ++k)
+      if (side[k]) hipStreamDestroy(side[k]);
   };
   if (!ok) {
     cleanup();
@@ -363,8 +406,8 @@ int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void
     cleanup();
     return fail(PF_ERR_HIP, "hipStreamBeginCapture failed");
   }
-  for (int i = 0; rc == PF_OK && i < iters_per_graph; ++i)
-    rc = enqueue_iteration_forked(p, s, side, ev[2 * i], ev[2 * i + 1]);
+  pf_capture cap{s, side[0], side[1], ev};
+  rc = enqueue_graph_iterations(p, iters_per_graph, cap);
   const hipError_t e = hipStreamEndCapture(s, &graph);
   cleanup();
   if (rc != PF_OK) {

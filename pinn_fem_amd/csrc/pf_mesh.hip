@@ -593,7 +593,7 @@ int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s) {
 
 // ---- multi-GPU launchers ---------------------------------------------------------------------------
 int pf_launch_iface_pack(const pf_problem* p, const float* vec, float* iface, hipStream_t s) {
-  if (hipMemsetAsync(iface, 0, (size_t)p->n_iface * sizeof(float), s) != hipSuccess) return PF_ERR_HIP;
+  if (p->n_iface > 0 && hipMemsetAsync(iface, 0, (size_t)p->n_iface * sizeof(float), s) != hipSuccess) return PF_ERR_HIP;
   if (p->n_shared > 0)
     hipLaunchKernelGGL(k_iface_pack, dim3((p->n_shared + 255) / 256), dim3(256), 0, s, *p, vec, iface);
   return PF_CHECK_LAUNCH();

@@ -109,9 +109,17 @@ __device__ __forceinline__ void load_input44(float (&x)[4], const float* __restr
 }
 
 // forward through the net; h[l][k] tanh activations, returns pre-softplus output z
+// output-unit weights [HP] + bias, wave-uniform: held in scalar registers for the whole kernel
+__device__ __forceinline__ void load_out_weights(float (&wo)[HP + 1], const float* __restrict__ w, int L) {
+  sfor<0, HP + 1>([&](auto k) {
+    constexpr int K = k;
+    wo[K] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, w[pf_pad_wo(HP, L) + K])));
+  });
+}
+
 template <int L, int IN, int NV>
-__device__ __forceinline__ float mlp_forward44(const float (&wv)[NV], const float (&x)[4],
-                                               float (&h)[L][HP]) {
+__device__ __forceinline__ float mlp_forward44(const float (&wv)[NV], const float (&wo)[HP + 1],
+                                               const float (&x)[4], float (&h)[L][HP]) {
   using W = WIdx<L>;
   // PHASES.  On gfx950 an f32 MFMA and f32 VALU share one pipe and every MFMA<->VALU switch in the
   // issue stream costs tens of cycles (tools/mfma_rate.hip); left alone, the scheduler interleaves
@@ -156,25 +164,29 @@ __device__ __forceinline__ float mlp_forward44(const float (&wv)[NV], const floa
     });
     PF_PHASE();
   });
-  // output unit: 4 partial chains to keep the MFMA pipe busy, summed at the end
-  f32x4 ao[4];
-  sfor<0, 4>([&](auto q) { constexpr int Q = q; ao[Q] = f32x4{0.f, 0.f, 0.f, 0.f}; });
-  ao[0] = MFMA44(W::fo(HP), 1.0f, ao[0]);
-  sfor<0, HP>([&](auto k) { constexpr int K = k; ao[(K + 1) % 4] = MFMA44(W::fo(K), h[L - 1][K], ao[(K + 1) % 4]); });
+  // output unit on the vector ALU: one row of weights (scalar loads, uniform address) against the own
+  // activations.  Same four fma chains and the same final sum as the former MFMA form (an f32 MFMA is
+  // a chain of fmaf, bitwise), at a quarter of its issue cycles: a 4x4x1 spends 4 rows on this 1-row product.
+  float ao[4];
+  ao[0] = wo[HP];                                      // 0 + bias*1
+  ao[1] = ao[2] = ao[3] = 0.f;
+  sfor<0, HP>([&](auto k) { constexpr int K = k; ao[(K + 1) % 4] = fmaf(wo[K], h[L - 1][K], ao[(K + 1) % 4]); });
   PF_PHASE();
-  return (ao[0][0] + ao[1][0]) + (ao[2][0] + ao[3][0]);
+  return (ao[0] + ao[1]) + (ao[2] + ao[3]);
 }
 
 // ---- forward kernel --------------------------------------------------------------------------------
 template <int L, int IN>
 __global__ __launch_bounds__(256) void k_net44_forward(pf_problem P, int which) {
-  if (P.state->done) return;
   const pf_net net = P.net[which];
   const float* __restrict__ w = P.theta_pad + net.pad_off;
   float* __restrict__ out = which == 0 ? P.prop_e : P.prop_a;
   constexpr int NV = WIdx<L>::NV_FWD;
   float wv[NV];
-  load_weights<NV, L>(wv, w, threadIdx.x & 63);
+  load_weights<NV, L>(wv, w, threadIdx.x & 63);   // issued before the stop flag is waited for
+  float wo[HP + 1];
+  load_out_weights(wo, w, L);
+  if (P.state->done) return;
   const int n = P.mesh.n_elems;
   // block-uniform trip count: every lane of a wave executes the same MFMAs (EXEC all ones)
   for (int base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256) void k_net44_forward(pf_problem P, int which) 
     const bool live = e < n;
     float x[4], h[L][HP];
     load_input44<IN>(x, P.mesh.ecent, e, P.lam, live);
-    const float z = mlp_forward44<L, IN, NV>(wv, x, h);
+    const float z = mlp_forward44<L, IN, NV>(wv, wo, x, h);
     if (live) out[e] = (net.positive ? pf_softplus(z) : z) * net.scale;
   }
 }
@@ -228,14 +240,73 @@ struct Row {
 constexpr int BW_THREADS = PF_NET_THREADS;
 constexpr int BW_WAVES = BW_THREADS / 64;
 
+// Inputs of one task (64 elements per wave), fetched ONE TASK AHEAD so that no global-memory latency
+// sits between two tasks of a wave (two waves per SIMD cannot hide it: measured 28 % of the wave
+// lifetime in s_waitcnt before this).
+template <int DIM>
+struct TaskIn {
+  float x[4];
+  float oth, gea;
+  int2 nn;
+  ElemGeo g;
+  float ui[2], uj[2], gi[2], gj[2];
+};
+
+// stage A of the fetch: everything addressed by the element id
+template <int IN, bool GEA>
+__device__ __forceinline__ void task_fetch_a(TaskIn<IN - 1>& t, const pf_problem& P, const pf_net& onet,
+                                             const float* __restrict__ other, int e, bool live) {
+  load_input44<IN>(t.x, P.mesh.ecent, e, P.lam, live);
+  t.oth = onet.scale;
+  t.gea = 0.f;
+  t.nn = int2{0, 0};
+  t.g = ElemGeo{0.f, 0.f, 0.f, 1.f};
+  if (!live) return;
+  if (onet.enabled) t.oth = other[e];
+  if (GEA) {
+    t.nn = reinterpret_cast<const int2*>(P.mesh.conn)[e];
+    t.g = load_geo(P.mesh.egeo, e);
+  } else {
+    t.gea = P.g_ea[e];
+  }
+}
+
+// stage B: the nodal gathers behind the connectivity (GEA only)
+template <int IN, bool GEA>
+__device__ __forceinline__ void task_fetch_b(TaskIn<IN - 1>& t, const pf_problem& P) {
+  constexpr int DIM = IN - 1;
+  if (!GEA) return;
+  load_vec<DIM>(P.u, t.nn.x, t.ui);
+  load_vec<DIM>(P.u, t.nn.y, t.uj);
+  load_vec<DIM>(P.g_f, t.nn.x, t.gi);
+  load_vec<DIM>(P.g_f, t.nn.y, t.gj);
+}
+
+// dL/d(E*A) from the fetched operands: the arithmetic of pf_elem_gea (pf_common.h), op for op
+template <int DIM>
+__device__ __forceinline__ float task_gea(const TaskIn<DIM>& t, int fe_mode) {
+  float pu0[2], pu1[2];
+  ke_rows_times<DIM>(t.g, 1.f, 0, t.ui, t.uj, pu0, fe_mode);
+  ke_rows_times<DIM>(t.g, 1.f, 1, t.ui, t.uj, pu1, fe_mode);
+  float gs = 0.f;
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) gs = fmaf(t.gi[c], pu0[c], gs);
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) gs = fmaf(t.gj[c], pu1[c], gs);
+  return gs / t.g.l0;
+}
+
 // GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the
 // other net's backward: saves the separate k_elem_adjoint pass in the fused iteration.
+// Two waves per SIMD are resident (grid <= 1023 blocks of 2 waves on 1024 SIMDs; LDS would allow 2.5), so
+// the register budget is the full 256: no scratch spills, room for the prefetched task and for
+// double-buffered gradient-tile operands.
 template <int L, int IN, bool GEA>
-__global__ __launch_bounds__(BW_THREADS, (L <= 2 ? 3 : 2)) void k_net44_backward(pf_problem P, int which) {
-  if (P.state->done) return;
+__global__ __launch_bounds__(BW_THREADS, 2) void k_net44_backward(pf_problem P, int which) {
   extern __shared__ __align__(16) float lds[];
   using W = WIdx<L>;
   using R = Row<L>;
+  constexpr int DIM = IN - 1;
   constexpr int NV = W::NV_ALL;
   constexpr int PADC = pf_pad_count(HP, L);
   constexpr int M = R::M;
@@ -243,15 +314,23 @@ __global__ __launch_bounds__(BW_THREADS, (L <= 2 ? 3 : 2)) void k_net44_backward
   const pf_net onet = P.net[1 - which];
   const float* __restrict__ w = P.theta_pad + net.pad_off;
   const float* __restrict__ other = which == 0 ? P.prop_a : P.prop_e;
-  const float* __restrict__ g_ea = P.g_ea;
   const int n = P.mesh.n_elems;
   const int lane = threadIdx.x & 63, wvid = threadIdx.x >> 6;
 
   float wv[NV];
   load_weights<NV, L>(wv, w, lane);
+  float wo[HP + 1];
+  load_out_weights(wo, w, L);
+  // first task's operands go out together with the weights, ahead of the stop-flag test
+  const int stride = gridDim.x * BW_THREADS;
+  int base = blockIdx.x * BW_THREADS;
+  TaskIn<DIM> nxt;
+  task_fetch_a<IN, GEA>(nxt, P, onet, other, base + (int)threadIdx.x, base + (int)threadIdx.x < n);
+  if (P.state->done) return;
+  task_fetch_b<IN, GEA>(nxt, P);
 
   // LDS: one pass = 32 elements, column-major (R::CS floats per column); two passes per 64-element
-  // batch keep the footprint at 13.8 kB per wave for a 20-20 net, so 3 waves per SIMD stay resident
+  // batch keep the footprint at 13.8 kB per wave for a 20-20 net
   constexpr int ROWS = 32;
   float* cols = lds + wvid * R::LEN * R::CS;
   float* mycol = cols + (lane & (ROWS - 1));       // + c*CS addresses column c of this lane's element
@@ -279,23 +358,29 @@ __global__ __launch_bounds__(BW_THREADS, (L <= 2 ? 3 : 2)) void k_net44_backward
     sfor<1, L + 1>([&](auto l) { constexpr int LL = l; mycol[(R::HE + (LL - 1) * (HP + 4) + HP) * R::CS] = 1.f; });
   }
 
-  for (int base = blockIdx.x * BW_THREADS; base < n; base += gridDim.x * BW_THREADS) {
+  for (; base < n; base += stride) {
     const int e = base + threadIdx.x;
     const bool live = e < n;
-    float x[4], h[L][HP];
-    load_input44<IN>(x, P.mesh.ecent, e, P.lam, live);
-    const float z = mlp_forward44<L, IN, NV>(wv, x, h);
+    const TaskIn<DIM> cur = nxt;
+    // stage A of the NEXT task's fetch goes out now; its stage B after this task's forward recompute
+    const int e_nxt = e + stride;
+    const bool more = base + stride < n;           // wave-uniform
+    if (more) task_fetch_a<IN, GEA>(nxt, P, onet, other, e_nxt, e_nxt < n);
+    PF_PHASE();
+    float h[L][HP];
+    const float z = mlp_forward44<L, IN, NV>(wv, wo, cur.x, h);
+    if (more) task_fetch_b<IN, GEA>(nxt, P);
+    PF_PHASE();
     float gz = 0.f;
     if (live) {
-      const float oth = onet.enabled ? other[e] : onet.scale;
       float gea;
       if (GEA) {
-        gea = pf_elem_gea<IN - 1>(P, e);
+        gea = task_gea<DIM>(cur, P.fe_mode);
         P.g_ea[e] = gea;
       } else {
-        gea = g_ea[e];
+        gea = cur.gea;
       }
-      float g = gea * oth;       // mul backward of young*area        (nn_assembly.py:74)
+      float g = gea * cur.oth;   // mul backward of young*area        (nn_assembly.py:74)
       g = g * net.scale;         // output*scale backward              (properties.py:156)
       gz = net.positive ? g * pf_softplus_grad(z) : g;
     }
@@ -346,7 +431,7 @@ __global__ __launch_bounds__(BW_THREADS, (L <= 2 ? 3 : 2)) void k_net44_backward
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
       if ((lane >> 5) == hf) {
-        sfor<0, 4>([&](auto c) { constexpr int C = c; mycol[(R::XE + C) * R::CS] = x[C]; });
+        sfor<0, 4>([&](auto c) { constexpr int C = c; mycol[(R::XE + C) * R::CS] = cur.x[C]; });
         mycol[R::DZO * R::CS] = gz;
         sfor<1, L + 1>([&](auto l) {
           constexpr int LL = l;
@@ -363,32 +448,42 @@ __global__ __launch_bounds__(BW_THREADS, (L <= 2 ? 3 : 2)) void k_net44_backward
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       PF_PHASE();
-#pragma unroll 2
-      for (int q4 = 0; q4 < ROWS / 4; ++q4) {
-        float4 av[M], bv[M];
+      // operands of step q4+1 are read while the 4*M MFMAs of step q4 issue (two register sets)
+      float4 av[2][M], bv[2][M];
+      sfor<0, M>([&](auto m) {
+        constexpr int MM = m;
+        av[0][MM] = *reinterpret_cast<const float4*>(pa[MM]);
+        bv[0][MM] = *reinterpret_cast<const float4*>(pb[MM]);
+      });
+      sfor<0, ROWS / 4>([&](auto q) {
+        constexpr int Q4 = q;
+        constexpr int CB = Q4 & 1, NBUF = 1 - CB;
+        if constexpr (Q4 + 1 < ROWS / 4) {
+          sfor<0, M>([&](auto m) {
+            constexpr int MM = m;
+            av[NBUF][MM] = *reinterpret_cast<const float4*>(pa[MM] + 4 * (Q4 + 1));
+            bv[NBUF][MM] = *reinterpret_cast<const float4*>(pb[MM] + 4 * (Q4 + 1));
+          });
+        }
+        PF_PHASE();
         sfor<0, M>([&](auto m) {
           constexpr int MM = m;
-          av[MM] = *reinterpret_cast<const float4*>(pa[MM] + 4 * q4);
-          bv[MM] = *reinterpret_cast<const float4*>(pb[MM] + 4 * q4);
+          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[CB][MM].x, bv[CB][MM].x, accw[MM], 0, 0, 0);
         });
         sfor<0, M>([&](auto m) {
           constexpr int MM = m;
-          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MM].x, bv[MM].x, accw[MM], 0, 0, 0);
+          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[CB][MM].y, bv[CB][MM].y, accw[MM], 0, 0, 0);
         });
         sfor<0, M>([&](auto m) {
           constexpr int MM = m;
-          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MM].y, bv[MM].y, accw[MM], 0, 0, 0);
+          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[CB][MM].z, bv[CB][MM].z, accw[MM], 0, 0, 0);
         });
         sfor<0, M>([&](auto m) {
           constexpr int MM = m;
-          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MM].z, bv[MM].z, accw[MM], 0, 0, 0);
+          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[CB][MM].w, bv[CB][MM].w, accw[MM], 0, 0, 0);
         });
-        sfor<0, M>([&](auto m) {
-          constexpr int MM = m;
-          accw[MM] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[MM].w, bv[MM].w, accw[MM], 0, 0, 0);
-        });
-      }
-      PF_PHASE();
+        PF_PHASE();
+      });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -269,7 +269,7 @@ class HipShardBackend(ShardBackend):
         lo2, hi2 = buf2.data_ptr(), buf2.data_ptr() + 4 * buf2.numel()
         for t in tensors:
             p = t.data_ptr()
-            if not (lo1 <= p < hi1 or lo2 <= p < hi2):
+            if t.numel() and not (lo1 <= p < hi1 or lo2 <= p < hi2):
                 raise ValueError("HipShardBackend works on its own collective buffers (backend.bufs)")
 
     def forward_residual(self):
