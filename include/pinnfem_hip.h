@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 1
+#define PF_ABI_VERSION 2
 
 /* error codes */
 #define PF_OK 0
@@ -143,9 +143,19 @@ typedef struct pf_problem {
   const int32_t* shared_slot; /* dev [n_shared] position in the global interface vector */
   int32_t n_shared;
   int32_t n_iface;         /* length of the global interface vector */
+  /* local elements incident to a shared node, ascending (evaluated ahead of the rest so that the
+   * interface all-reduce overlaps the full forward pass); NULL / 0 on one GPU */
+  const int32_t* iface_elems;
+  int32_t n_iface_elems;
+  int32_t _pad_iface;
 } pf_problem;
 
 #define PF_MAX_BLOCKS 1024
+/* node-parallel kernels run one node per thread on up to PF_MAX_NODE_BLOCKS blocks of 256 threads;
+ * each block owns one slot of the three scalar partial-sum arrays (PF_NODE_SLOTS floats each, one
+ * extra slot for the multi-GPU interface dofs) at the head of `partials` */
+#define PF_MAX_NODE_BLOCKS 4096
+#define PF_NODE_SLOTS (PF_MAX_NODE_BLOCKS + 8)
 
 /* ---- introspection ------------------------------------------------------------------ */
 int pf_abi_version(void);
@@ -235,22 +245,51 @@ int pf_adam_theta(const pf_problem* p, void* stream);
  * and sum_u2 (dev, 1 float) */
 int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* sum_u2, void* stream);
 
-/* The same steps grouped between the three collectives of one sharded iteration, so the host makes
- * four calls per iteration instead of ~20 (pinn_fem_amd/dist.py):
- *   phase1: nets forward, node_residual (f_int -> fbuf), pack f_int interface        -> all-reduce(iface1)
- *   phase2: fix residual, element adjoint, nets backward, node_gradu, theta reduce (into
- *           p->grad_theta, which the host points inside buf2), pack grad_u interface,
- *           local sums -> buf2 = [iface | grad_theta | r2, d2, -]                     -> all-reduce(buf2)
- *   phase3: unpack grad_u interface, Adam(u)+clamp, Adam(theta), local sums -> u2[3]  -> all-reduce(u2)
- *   phase4: pf_finalize_from(buf2 tail, u2+2) */
-int pf_shard_phase1(const pf_problem* p, float* fbuf, float* iface1, void* stream);
-int pf_shard_phase2(const pf_problem* p, const float* iface1, float* buf2, void* stream);
-int pf_shard_phase3(const pf_problem* p, const float* buf2, float* u2, void* stream);
-/* hipGraph form of the three phases (same contract as pf_graph_create: the record and the buffer
- * pointers are baked in).  graphs_out receives 3 opaque handles (phase 1, 2, 3) for pf_graph_launch /
- * pf_graph_destroy. */
-int pf_shard_graphs_create(const pf_problem* p, float* fbuf, float* iface1, float* buf2, float* sums3,
-                           void* stream, void** graphs_out);
+/* One sharded iteration = five phases in stream order around TWO small all-reduces the host issues:
+ *   A  pf_shard_iface_forward   the nets on the interface elements only (same arithmetic as the full
+ *                               kernels, bit for bit) and the partial f_int of the shared dofs
+ *                               -> iface1[slot]                                      => all-reduce(buf1)
+ *   B  pf_shard_forward         the nets on all elements
+ *   C  pf_shard_backward        node_residual with the reduced f_int on shared dofs (sums by the owner),
+ *                               nets backward, theta reduction into p->grad_theta (which the host points
+ *                               inside buf2), partial grad_u of the shared dofs, local sums
+ *                               -> buf2 = [iface grad_u | grad_theta | r2, d2, 0]
+ *   D  pf_shard_update_interior grad_u + Adam(u) + clamp of every dof that is NOT shared  => all-reduce(buf2)
+ *   E  pf_shard_update_shared   Adam(theta) from the reduced gradient, Adam(u) of the shared dofs from
+ *                               buf2, sums3 = [0, 0, local sum u_free^2 of owned dofs]
+ * pf_finalize_from() of iteration t runs after all-reduce 1 of iteration t+1, which carries sums3 (before C).
+ * A comes first so that the first exchange needs only a one-block kernel, not the full forward pass.
+ * Requires p->n_iface_elems <= PF_MAX_IFACE_ELEMS (else phase A returns PF_ERR_UNSUPPORTED and the host
+ * runs B first and gathers the shared dofs with pf_internal_force + pf_iface_pack). */
+#define PF_MAX_IFACE_ELEMS 2048
+int pf_shard_iface_forward(const pf_problem* p, float* iface1, void* stream);
+int pf_shard_forward(const pf_problem* p, void* stream);
+int pf_shard_backward(const pf_problem* p, const float* iface1, float* buf2, void* stream);
+int pf_shard_update_interior(const pf_problem* p, void* stream);
+int pf_shard_update_shared(const pf_problem* p, const float* buf2, float* sums3, void* stream);
+/* Phases B, C and D (+ pf_finalize_from of the previous iteration when with_finalize) as ONE hipGraph
+ * with the single-GPU schedule's branches: bookkeeping beside the forwards, D beside backward #2 and the
+ * theta reduction.  buf1 = dev [3 + n_iface] (sums3 | iface1), buf2 as above; the record and the pointers
+ * are baked in.  Handle for pf_graph_launch / pf_graph_destroy. */
+int pf_shard_graph_create(const pf_problem* p, float* buf1, float* buf2, int with_finalize, void* stream,
+                          void** graph_out);
+
+/* The same iteration driven from C with an own RCCL communicator (pf_comm.hip): the product path on real
+ * multi-GPU runs.  librccl is dlopen'ed from `librccl_path` (the library PyTorch loaded; NULL/"" =
+ * "librccl.so"); there is no link-time dependency.
+ *   rank 0: pf_comm_unique_id -> 128 bytes, broadcast by the host (torch.distributed) -> every rank:
+ *   pf_comm_create (collective, like ncclCommInitRank).
+ * pf_shard_iterations enqueues n_iter iterations on `stream` — A, ncclAllReduce(buf1), the graph of
+ * pf_shard_graph_create (graph_first for the first iteration of the call, graph_next after it; both NULL:
+ * the phases one by one), ncclAllReduce(buf2), E — plus the closing flush + bookkeeping, and returns
+ * without waiting for the device.  buf1 = dev [3 + n_iface], buf2 = dev [n_iface + n_theta_active + 3], and
+ * p->grad_theta must point at buf2 + n_iface. */
+#define PF_COMM_ID_BYTES 128
+int pf_comm_unique_id(const char* librccl_path, void* id_out);
+int pf_comm_create(const char* librccl_path, const void* id, int rank, int world, void** comm_out);
+int pf_comm_destroy(void* comm);
+int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf1, float* buf2,
+                        void* graph_first, void* graph_next, void* stream);
 
 /* ---- extensions (off the default path) ------------------------------------------------ */
 /* generic Adam (torch.optim.Adam single-tensor arithmetic) on a flat vector */

@@ -11,13 +11,17 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpinnfem_hip.so")
 
-PF_ABI_VERSION = 1
+PF_ABI_VERSION = 2
 PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_DOF_FIXED, PF_DOF_MEASURED, PF_DOF_SHARED, PF_DOF_GHOST = 1, 2, 4, 8
 PF_WG_SHUFFLE, PF_WG_MFMA, PF_WG_MFMA44 = 0, 1, 2
 PF_FE_REFERENCE, PF_FE_DELTA = 0, 1
 PF_HIST_COLS = 6
 PF_MAX_BLOCKS = 1024
+PF_MAX_IFACE_ELEMS = 2048
+PF_COMM_ID_BYTES = 128
+PF_MAX_NODE_BLOCKS = 4096
+PF_NODE_SLOTS = PF_MAX_NODE_BLOCKS + 8
 PF_KERNEL_SLOTS = 9
 KERNEL_SLOT_NAMES = ("net_forward_young", "net_forward_area", "node_residual", "elem_adjoint",
                      "net_backward_young", "net_backward_area", "node_gradu_adam", "theta_reduce_adam",
@@ -76,6 +80,7 @@ class PfProblem(C.Structure):
         ("n_meas_f", C.c_float), ("fe_mode", C.c_int32),
         ("shared_dofs", C.c_void_p), ("shared_slot", C.c_void_p),
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
+        ("iface_elems", C.c_void_p), ("n_iface_elems", C.c_int32), ("_pad_iface", C.c_int32),
     ]
 
 
@@ -113,11 +118,18 @@ SYMBOLS = {
     "pf_adam_u": (C.c_int, [_PP, C.c_void_p]),
     "pf_adam_theta": (C.c_int, [_PP, C.c_void_p]),
     "pf_finalize_from": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_shard_phase1": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_shard_phase2": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_shard_phase3": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_shard_graphs_create": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.POINTER(C.c_void_p)]),
+    "pf_shard_iface_forward": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
+    "pf_shard_forward": (C.c_int, [_PP, C.c_void_p]),
+    "pf_shard_backward": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_shard_update_interior": (C.c_int, [_PP, C.c_void_p]),
+    "pf_shard_update_shared": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_comm_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
+    "pf_comm_create": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "pf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pf_shard_iterations": (C.c_int, [_PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
+    "pf_shard_graph_create": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.POINTER(C.c_void_p)]),
     "pf_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pf_diag_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),

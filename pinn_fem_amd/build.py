@@ -21,11 +21,11 @@ LIB = os.path.join(HERE, "lib", "libpinnfem_hip.so")
 WIDTHS = (4, 8, 12, 16, 20, 24, 28, 32)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-         "-I" + CSRC, "-Wall", "-Wno-unused-function"]
+         "-I" + CSRC, "-I/opt/rocm/include", "-Wall", "-Wno-unused-function"]
 
 
 def _sources():
-    units = [("pf_api.o", "pf_api.hip", []), ("pf_mesh.o", "pf_mesh.hip", [])]
+    units = [("pf_api.o", "pf_api.hip", []), ("pf_mesh.o", "pf_mesh.hip", []), ("pf_comm.o", "pf_comm.hip", [])]
     # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
     # removes the v_accvgpr_read copies in front of every tanh
     units += [(f"pf_net44_{w}.o", "pf_net44.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
@@ -66,7 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if rc != 0:
                 raise RuntimeError(f"hipcc failed on {obj}:\n{log}")
     objs = [os.path.join(OBJ, u[0]) for u in units]
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)

@@ -1,13 +1,18 @@
 // pf_api.hip — the C ABI declared in include/pinnfem_hip.h: argument checks, net-shape dispatch,
 // and the fused GD-iteration launch sequence (FEM/python/fem/solver.py:254-355).
+#include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
 #include "pf_common.h"
 
 // launchers from pf_mesh.hip
-int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s);
+int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s,
+                            const float* iface = nullptr);
 int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s);
-int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s);
+int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared = 0);
+int pf_launch_iface_forward(const pf_problem* p, float* iface, hipStream_t s);
+int pf_launch_shard_pack(const pf_problem* p, float* buf2, hipStream_t s);
+int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* sums3, hipStream_t s);
 int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s);
 int pf_launch_pack_theta(const pf_problem* p, hipStream_t s);
 int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s);
@@ -321,9 +326,10 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
 // kernel at its start; a kernel of t+1 that misses a stop raised by finalize(t) only rewrites scratch
 // (properties, g_f, partial sums): everything that changes solver state (both Adam kernels, finalize)
 // is ordered behind finalize(t) and returns at once, so the final state is the reference's `break`.
+#define PF_CAP_EV 6
 struct pf_capture {
   hipStream_t s, a, b;
-  hipEvent_t* ev;   // 4 per iteration: u readers done | gradu done | theta done | finalize done
+  hipEvent_t* ev;   // PF_CAP_EV per iteration: u readers done | gradu done | theta done | finalize done | forward fork | join
 };
 
 static int cap_edge(hipEvent_t e, hipStream_t from, hipStream_t to) {
@@ -345,12 +351,24 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   const bool fuse_gea = p->wg_mode == PF_WG_MFMA44;
   const int first = p->net[0].enabled ? 0 : 1;
   for (int i = 0; i < iters; ++i) {
-    hipEvent_t* e = c.ev + 4 * i;
-    hipEvent_t* ep = c.ev + 4 * (i - 1);
+    hipEvent_t* e = c.ev + PF_CAP_EV * i;
+    hipEvent_t* ep = c.ev + PF_CAP_EV * (i - 1);
     // gradu(i-1) still reads the properties the forwards overwrite, and writes the u the residual reads
     if (i > 0 && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    for (int k = 0; k < 2; ++k)
-      if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+    // the two forwards are independent, but running the second on branch A beside the first measured
+    // SLOWER (0.195 vs 0.190 ms per iteration): both are bound by the same f32 pipe.  PF_FWD_PARALLEL=1 keeps
+    // the experiment reachable.
+    static const bool fwd_par = getenv("PF_FWD_PARALLEL") && atoi(getenv("PF_FWD_PARALLEL")) != 0;
+    const bool two = p->net[0].enabled && p->net[1].enabled && fwd_par;
+    if (two) {
+      if (cap_edge(e[4], s, c.a) != PF_OK) return PF_ERR_HIP;
+      PF_TRY(net_forward(p, 0, s), "net_forward");
+      PF_TRY(net_forward(p, 1, c.a), "net_forward");
+      if (cap_edge(e[5], c.a, s) != PF_OK) return PF_ERR_HIP;
+    } else {
+      for (int k = 0; k < 2; ++k)
+        if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+    }
     // finalize(i-1) reads the block partials node_residual rewrites, and writes the Adam scalars
     if (i > 0 && hipStreamWaitEvent(s, ep[3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
     PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
@@ -372,7 +390,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     if (hipEventRecord(e[3], c.b) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
   }
   // join: finalize of the last iteration is behind everything else
-  if (hipStreamWaitEvent(s, c.ev[4 * (iters - 1) + 3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
+  if (hipStreamWaitEvent(s, c.ev[PF_CAP_EV * (iters - 1) + 3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
   return PF_OK;
 }
 
@@ -384,7 +402,7 @@ int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   hipStream_t side[2] = {nullptr, nullptr};
-  const int nev = 4 * iters_per_graph;
+  const int nev = PF_CAP_EV * iters_per_graph;
   hipEvent_t* ev = new hipEvent_t[nev];
   int made = 0;
   bool ok = hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking) == hipSuccess &&
@@ -480,8 +498,6 @@ static int check_shared(const pf_problem* p) {
   if (rc) return rc;
   if (p->n_shared < 0 || p->n_iface < p->n_shared) return fail(PF_ERR_ARG, "bad interface sizes");
   if (p->n_shared > 0 && (!p->shared_dofs || !p->shared_slot)) return fail(PF_ERR_ARG, "null interface maps");
-  if (pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks) >= PF_MAX_BLOCKS)
-    return fail(PF_ERR_ARG, "multi-GPU needs n_part_blocks < PF_MAX_BLOCKS (one slot is reserved)");
   return PF_OK;
 }
 
@@ -541,25 +557,36 @@ int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* s
   return PF_OK;
 }
 
-int pf_shard_phase1(const pf_problem* p, float* fbuf, float* iface1, void* stream) {
+int pf_shard_iface_forward(const pf_problem* p, float* iface1, void* stream) {
   int rc = check_shared(p);
   if (rc) return rc;
-  if (!fbuf || !iface1) return fail(PF_ERR_ARG, "null fbuf / iface1");
-  hipStream_t s = (hipStream_t)stream;
-  for (int k = 0; k < 2; ++k)
-    if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
-  PF_TRY(pf_launch_node_residual(p, fbuf, 1, s), "node_residual");
-  PF_TRY(pf_launch_iface_pack(p, fbuf, iface1, s), "iface_pack");
+  if (!iface1) return fail(PF_ERR_ARG, "null iface1");
+  if (p->n_iface_elems < 0 || (p->n_iface_elems > 0 && !p->iface_elems))
+    return fail(PF_ERR_ARG, "bad interface element list");
+  if (p->n_iface_elems > PF_MAX_IFACE_ELEMS)
+    return fail(PF_ERR_UNSUPPORTED, "more interface elements than PF_MAX_IFACE_ELEMS: run the full forward first");
+  PF_TRY(pf_launch_iface_forward(p, iface1, (hipStream_t)stream), "iface_forward");
   return PF_OK;
 }
 
-int pf_shard_phase2(const pf_problem* p, const float* iface1, float* buf2, void* stream) {
+int pf_shard_forward(const pf_problem* p, void* stream) {
   int rc = check_shared(p);
   if (rc) return rc;
-  if (!iface1 || !buf2 || !p->grad_u) return fail(PF_ERR_ARG, "null iface1 / buf2 / grad_u");
+  hipStream_t s = (hipStream_t)stream;
+  for (int k = 0; k < 2; ++k)
+    if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+  return PF_OK;
+}
+
+int pf_shard_backward(const pf_problem* p, const float* iface1, float* buf2, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!iface1 || !buf2) return fail(PF_ERR_ARG, "null iface1 / buf2");
+  if (p->n_theta_active > 0 && p->grad_theta != buf2 + p->n_iface)
+    return fail(PF_ERR_ARG, "p->grad_theta must point at buf2 + n_iface");
   hipStream_t s = (hipStream_t)stream;
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
-  PF_TRY(pf_launch_iface_fix_residual(p, iface1, s), "iface_fix_residual");
+  PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, iface1), "node_residual");
   if (any_net) {
     const bool fuse_gea = p->wg_mode == PF_WG_MFMA44;
     const int first = p->net[0].enabled ? 0 : 1;
@@ -567,23 +594,26 @@ int pf_shard_phase2(const pf_problem* p, const float* iface1, float* buf2, void*
     for (int k = 0; k < 2; ++k)
       if (p->net[k].enabled)
         PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
+    PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
   }
-  PF_TRY(pf_launch_node_gradu(p, 0, s), "node_gradu");
-  if (any_net) PF_TRY(pf_launch_theta_reduce(p, 0, s), "theta_reduce");
-  PF_TRY(pf_launch_iface_pack(p, p->grad_u, buf2, s), "iface_pack");
-  PF_TRY(pf_launch_local_sums(p, buf2 + p->n_iface + p->n_theta_active, s), "local_sums");
+  PF_TRY(pf_launch_shard_pack(p, buf2, s), "shard_pack");
   return PF_OK;
 }
 
-int pf_shard_phase3(const pf_problem* p, const float* buf2, float* u2, void* stream) {
+int pf_shard_update_interior(const pf_problem* p, void* stream) {
   int rc = check_shared(p);
   if (rc) return rc;
-  if (!buf2 || !u2 || !p->grad_u || !p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null buffer");
-  hipStream_t s = (hipStream_t)stream;
-  PF_TRY(pf_launch_iface_unpack(p, buf2, p->grad_u, s), "iface_unpack");
-  PF_TRY(pf_launch_adam_u(p, s), "adam_u");
-  PF_TRY(pf_launch_adam_theta(p, s), "adam_theta");
-  PF_TRY(pf_launch_local_sums(p, u2, s), "local_sums");
+  if (!p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null Adam moments for u");
+  PF_TRY(pf_launch_node_gradu(p, 1, (hipStream_t)stream, 1), "node_gradu");
+  return PF_OK;
+}
+
+int pf_shard_update_shared(const pf_problem* p, const float* buf2, float* sums3, void* stream) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!buf2 || !sums3 || !p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null buffer");
+  if (p->n_theta_active > 0 && (!p->m_t || !p->v_t)) return fail(PF_ERR_ARG, "null Adam moments for theta");
+  PF_TRY(pf_launch_shard_update(p, buf2, sums3, (hipStream_t)stream), "shard_update");
   return PF_OK;
 }
 
@@ -611,19 +641,79 @@ static int capture_graph(hipStream_t s, F&& body, void** out) {
 }
 extern "C" {
 
-int pf_shard_graphs_create(const pf_problem* p, float* fbuf, float* iface1, float* buf2, float* sums3,
-                           void* stream, void** graphs_out) {
+// Phases B + C (+ the interior part of D) of one sharded iteration as ONE graph with the single-GPU
+// schedule's branches: the previous iteration's bookkeeping beside the forwards, grad_u + Adam(u) of the
+// dofs that are not shared beside backward #2 and the theta reduction.  Stream events between eager
+// launches cost ~9 us per record+wait pair on this runtime (measured: 35-40 us per iteration for the
+// four hops of an "overlapped" eager schedule), graph edges do not.
+int pf_shard_graph_create(const pf_problem* p, float* buf1, float* buf2, int with_finalize, void* stream,
+                          void** graph_out) {
   int rc = check_shared(p);
   if (rc) return rc;
-  if (!fbuf || !iface1 || !buf2 || !sums3 || !graphs_out) return fail(PF_ERR_ARG, "pf_shard_graphs_create: null argument");
+  if (!buf1 || !buf2 || !graph_out) return fail(PF_ERR_ARG, "pf_shard_graph_create: null argument");
+  if (!p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null Adam moments for u");
+  if (p->n_theta_active > 0 && p->grad_theta != buf2 + p->n_iface)
+    return fail(PF_ERR_ARG, "p->grad_theta must point at buf2 + n_iface");
   hipStream_t s = (hipStream_t)stream;
-  graphs_out[0] = graphs_out[1] = graphs_out[2] = nullptr;
-  rc = capture_graph(s, [&]() { return pf_shard_phase1(p, fbuf, iface1, stream); }, &graphs_out[0]);
-  if (rc == PF_OK) rc = capture_graph(s, [&]() { return pf_shard_phase2(p, iface1, buf2, stream); }, &graphs_out[1]);
-  if (rc == PF_OK) rc = capture_graph(s, [&]() { return pf_shard_phase3(p, buf2, sums3, stream); }, &graphs_out[2]);
-  if (rc != PF_OK)
-    for (int i = 0; i < 3; ++i)
-      if (graphs_out[i]) { hipGraphExecDestroy((hipGraphExec_t)graphs_out[i]); graphs_out[i] = nullptr; }
+  hipStream_t side[2] = {nullptr, nullptr};
+  hipEvent_t ev[5];
+  int made = 0;
+  bool ok = hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&side[1], hipStreamNonBlocking) == hipSuccess;
+  for (; ok && made < 5; ++made)
+    if (hipEventCreateWithFlags(&ev[made], hipEventDisableTiming) != hipSuccess) break;
+  ok = ok && made == 5;
+  auto cleanup = [&]() {
+    for (int i = 0; i < made; ++i) hipEventDestroy(ev[i]);
+    for (int k = 0; k < 2; ++k)
+      if (side[k]) hipStreamDestroy(side[k]);
+  };
+  if (!ok) {
+    cleanup();
+    return fail(PF_ERR_HIP, "pf_shard_graph_create: stream/event creation failed");
+  }
+  const float* iface1 = buf1 + 3;
+  const float* r2d2 = buf2 + p->n_iface + p->n_theta_active;
+  hipStream_t fin = side[0], gu = side[1];
+  rc = capture_graph(s, [&]() -> int {
+    const bool any_net = p->net[0].enabled || p->net[1].enabled;
+    const bool fuse_gea = any_net && p->wg_mode == PF_WG_MFMA44;
+    const int first = p->net[0].enabled ? 0 : 1;
+    // branch `fin`: bookkeeping of the previous iteration from the reduced sums (buf1[2], tail of buf2)
+    if (with_finalize) {
+      if (cap_edge(ev[0], s, fin) != PF_OK) return PF_ERR_HIP;
+      PF_TRY(pf_launch_finalize_from(p, r2d2, buf1 + 2, fin), "finalize_from");
+      if (hipEventRecord(ev[1], fin) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    }
+    for (int k = 0; k < 2; ++k)
+      if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, iface1), "node_residual");
+    if (any_net && !fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+    bool forked = false;
+    auto fork_gradu = [&]() -> int {   // after the last reader of u; behind the bookkeeping (Adam scalars)
+      if (cap_edge(ev[2], s, gu) != PF_OK) return PF_ERR_HIP;
+      if (with_finalize && hipStreamWaitEvent(gu, ev[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+      PF_TRY(pf_launch_node_gradu(p, 1, gu, 1), "node_gradu");
+      if (hipEventRecord(ev[3], gu) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+      forked = true;
+      return PF_OK;
+    };
+    if (!fuse_gea) { int r = fork_gradu(); if (r != PF_OK) return r; }
+    if (any_net) {
+      for (int k = 0; k < 2; ++k) {
+        if (!p->net[k].enabled) continue;
+        PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
+        if (fuse_gea && k == first) { int r = fork_gradu(); if (r != PF_OK) return r; }
+      }
+      PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
+    }
+    // the pack kernel rewrites the tail of buf2 the bookkeeping reads
+    if (with_finalize && hipStreamWaitEvent(s, ev[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    PF_TRY(pf_launch_shard_pack(p, buf2, s), "shard_pack");
+    if (forked && hipStreamWaitEvent(s, ev[3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
+    return PF_OK;
+  }, graph_out);
+  cleanup();
   return rc;
 }
 

@@ -1,0 +1,149 @@
+// pf_comm.hip — the sharded GD iteration driven from C with an own RCCL communicator.
+//
+// No reference analogue (the reference is single-process).  pinn_fem_amd/dist.py holds the
+// same schedule in Python over torch.distributed (used with gloo on CPU and for several ranks sharing one
+// GPU in tests); on real multi-GPU runs that loop is HOST-bound (5 graph replays + 2 torch collectives
+// per iteration ~ 280 us of host time against ~220 us of GPU time, measured on MI355X), so the product
+// path issues the kernels and the two ncclAllReduce per iteration from here: a handful of launches, no Python.
+//
+// librccl is dlopen'ed from the path the host passes (the one PyTorch already loaded: same library
+// instance, second communicator); there is no link-time dependency on it.
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <rccl/rccl.h>
+#include "pf_common.h"
+
+struct pf_comm {
+  void* dl;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*);
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+  ncclResult_t (*CommDestroy)(ncclComm_t);
+  const char* (*GetErrorString)(ncclResult_t);
+  ncclComm_t comm;
+  int rank, world;
+};
+
+static int comm_fail(int code, const char* what, const char* detail) {
+  char buf[400];
+  snprintf(buf, sizeof(buf), "%s: %s", what, detail ? detail : "");
+  pf_set_error(buf);
+  return code;
+}
+
+static int load_rccl(pf_comm* c, const char* path) {
+  c->dl = dlopen(path && path[0] ? path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!c->dl) return comm_fail(PF_ERR_HIP, "dlopen(librccl)", dlerror());
+#define PF_SYM(field, name)                                                     \
+  *(void**)(&c->field) = dlsym(c->dl, name);                                    \
+  if (!c->field) return comm_fail(PF_ERR_HIP, "dlsym", name);
+  PF_SYM(GetUniqueId, "ncclGetUniqueId")
+  PF_SYM(CommInitRank, "ncclCommInitRank")
+  PF_SYM(AllReduce, "ncclAllReduce")
+  PF_SYM(CommDestroy, "ncclCommDestroy")
+  PF_SYM(GetErrorString, "ncclGetErrorString")
+#undef PF_SYM
+  return PF_OK;
+}
+
+extern "C" {
+
+int pf_comm_unique_id(const char* librccl_path, void* id_out) {
+  if (!id_out) return comm_fail(PF_ERR_ARG, "pf_comm_unique_id", "null id_out");
+  pf_comm c;
+  memset(&c, 0, sizeof(c));
+  int rc = load_rccl(&c, librccl_path);
+  if (rc) return rc;
+  ncclUniqueId id;
+  const ncclResult_t r = c.GetUniqueId(&id);
+  if (r != ncclSuccess) return comm_fail(PF_ERR_HIP, "ncclGetUniqueId", c.GetErrorString(r));
+  memcpy(id_out, &id, sizeof(id));
+  return PF_OK;     // the dlopen handle stays: the library is resident for the process lifetime anyway
+}
+
+int pf_comm_create(const char* librccl_path, const void* id, int rank, int world, void** comm_out) {
+  if (!id || !comm_out || world < 1 || rank < 0 || rank >= world)
+    return comm_fail(PF_ERR_ARG, "pf_comm_create", "bad argument");
+  pf_comm* c = new pf_comm;
+  memset(c, 0, sizeof(*c));
+  int rc = load_rccl(c, librccl_path);
+  if (rc) { delete c; return rc; }
+  ncclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  const ncclResult_t r = c->CommInitRank(&c->comm, world, uid, rank);   // collective: every rank calls it
+  if (r != ncclSuccess) {
+    rc = comm_fail(PF_ERR_HIP, "ncclCommInitRank", c->GetErrorString(r));
+    delete c;
+    return rc;
+  }
+  c->rank = rank;
+  c->world = world;
+  *comm_out = c;
+  return PF_OK;
+}
+
+int pf_comm_destroy(void* comm) {
+  if (!comm) return PF_OK;
+  pf_comm* c = (pf_comm*)comm;
+  c->CommDestroy(c->comm);
+  delete c;
+  return PF_OK;
+}
+
+// sum over ranks of buf[0..n), in place, on the compute stream.  The interface vectors are a few hundred
+// bytes to ~4 kB: the collective is latency bound, and hiding it on a second stream costs more than it
+// saves on this runtime (cross-stream event pairs between eager launches: ~9 us each, four per iteration;
+// measured with PF_COMM_MODE-style variants on MI355X: 0.261 ms overlapped vs 0.228 ms in stream order).
+static int all_reduce(pf_comm* c, float* buf, size_t n, hipStream_t s) {
+  const ncclResult_t r = c->AllReduce(buf, buf, n, ncclFloat, ncclSum, c->comm, s);
+  if (r != ncclSuccess) return comm_fail(PF_ERR_HIP, "ncclAllReduce", c->GetErrorString(r));
+  return PF_OK;
+}
+
+#define PF_RUN(expr)          \
+  do {                        \
+    int rc__ = (expr);        \
+    if (rc__ != PF_OK) return rc__; \
+  } while (0)
+
+// n_iter sharded iterations and the closing flush, everything in stream order on `stream`:
+//   A (eager)  ->  all-reduce(buf1)  ->  graph [B, C, interior part of D; pf_shard_graph_create]
+//   ->  all-reduce(buf2)  ->  E (eager)
+// graph_first / graph_next: the graph without / with the previous iteration's bookkeeping (NULL: the phases
+// are launched one by one, no branches).  buf1 = [0, 0, sum u^2 | iface f_int (n_iface)],
+// buf2 = [iface grad_u | grad_theta | r2, d2, 0].  Nothing here waits for the device.
+int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf1, float* buf2,
+                        void* graph_first, void* graph_next, void* stream) {
+  if (!p || !comm || !buf1 || !buf2 || n_iter < 0) return comm_fail(PF_ERR_ARG, "pf_shard_iterations", "bad argument");
+  pf_comm* c = (pf_comm*)comm;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n1 = 3 + (size_t)p->n_iface, n2 = (size_t)p->n_iface + (size_t)p->n_theta_active + 3;
+  float* iface1 = buf1 + 3;
+  const float* r2d2 = buf2 + p->n_iface + p->n_theta_active;
+  const bool graphs = graph_first && graph_next;
+  bool pending = false;
+  for (int it = 0; it < n_iter; ++it) {
+    PF_RUN(pf_shard_iface_forward(p, iface1, stream));                  // A
+    PF_RUN(all_reduce(c, buf1, n1, s));                                 // (1)
+    if (graphs) {
+      PF_RUN(pf_graph_launch(pending ? graph_next : graph_first, stream));
+    } else {
+      PF_RUN(pf_shard_forward(p, stream));                              // B
+      if (pending) PF_RUN(pf_finalize_from(p, r2d2, buf1 + 2, stream)); // bookkeeping of the previous iteration
+      PF_RUN(pf_shard_backward(p, iface1, buf2, stream));               // C
+      PF_RUN(pf_shard_update_interior(p, stream));                      // D
+    }
+    PF_RUN(all_reduce(c, buf2, n2, s));                                 // (2)
+    PF_RUN(pf_shard_update_shared(p, buf2, buf1, stream));              // E
+    pending = true;
+  }
+  if (pending) {
+    PF_RUN(all_reduce(c, buf1, 3, s));                                  // flush: the last iteration's sum u^2
+    PF_RUN(pf_finalize_from(p, r2d2, buf1 + 2, stream));
+  }
+  return PF_OK;
+}
+
+}  // extern "C"

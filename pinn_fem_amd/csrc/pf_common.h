@@ -7,12 +7,12 @@
 #define PF_WAVE 64
 
 // ---- partial-sum workspace layout (floats) -------------------------------------------
-// [0, 3*PF_MAX_BLOCKS)            : per-block scalar partials  (sum r^2 | sum d^2 | sum u_free^2)
-// [3*PF_MAX_BLOCKS, ...)          : per-block padded weight-gradient rows [n_blocks][pad_total]
+// [0, 3*PF_NODE_SLOTS)            : per-node-block scalar partials  (sum r^2 | sum d^2 | sum u_free^2)
+// [3*PF_NODE_SLOTS, ...)          : per-block padded weight-gradient rows [n_part_blocks][pad_total]
 #define PF_PART_R2 0
-#define PF_PART_D2 (PF_MAX_BLOCKS)
-#define PF_PART_U2 (2 * PF_MAX_BLOCKS)
-#define PF_PART_WG (3 * PF_MAX_BLOCKS)
+#define PF_PART_D2 (PF_NODE_SLOTS)
+#define PF_PART_U2 (2 * PF_NODE_SLOTS)
+#define PF_PART_WG (3 * PF_NODE_SLOTS)
 // after the [n_part_blocks][pad_total] rows: [PF_RG][pad_total] second-level partial rows
 #define PF_RG 16
 
@@ -196,13 +196,9 @@ __host__ __device__ inline int pf_net_blocks(int n_elems, int n_part_blocks) {
   if (nb < 1) nb = 1;
   return nb;
 }
-// blocks the node-parallel kernels launch
-__host__ __device__ inline int pf_node_blocks(int n_nodes, int n_part_blocks) {
-  int nb = (n_nodes + PF_NODE_THREADS - 1) / PF_NODE_THREADS;
-  if (nb > n_part_blocks) nb = n_part_blocks;
-  if (nb < 1) nb = 1;
-  return nb;
-}
+// blocks the node-parallel kernels launch (grid-stride over nodes, at most PF_MAX_NODE_BLOCKS: one
+// partial-sum slot per block; pf_mesh.hip)
+int pf_node_blocks(int n_nodes);
 
 // launchers implemented once per padded width in pf_net.hip (compiled with -DPF_HP=<hp>)
 #define PF_DECL_NET_LAUNCHERS(HP)                                                         \
@@ -221,3 +217,4 @@ PF_DECL_NET_LAUNCHERS(28)
 PF_DECL_NET_LAUNCHERS(32)
 
 void pf_set_error(const char* msg);
+

@@ -13,7 +13,15 @@
 // replaced by an owner-computes GATHER: one thread per node walks the node's incident elements in
 // ascending element id, which reproduces the reference's accumulation order exactly, needs no
 // atomics and is bitwise reproducible.  K is never formed: K u and K^T g are applied matrix-free.
+#include <stdlib.h>
 #include "pf_common.h"
+
+// torch.optim.Adam is a sequence of separately rounded tensor ops (lerp_, mul_, addcmul_, sqrt, div, add,
+// addcdiv_); with the default -ffp-contract=fast hipcc fuses some of them into fma, and not the same ones in
+// every inlined copy (measured: the hipGraph path, which runs theta_stage2 as its own kernel, and the eager
+// path, which runs it inside k_finalize, drifted apart by 1 ulp in theta).  Contraction is switched off in
+// every function that carries optimiser arithmetic.
+#define PF_NO_CONTRACT _Pragma("clang fp contract(off)")
 
 namespace {
 
@@ -40,10 +48,24 @@ __device__ __forceinline__ void gather_kv(const pf_problem& P, const float* __re
   }
 }
 
+// position of `dof` in the ascending shared_dofs list (multi-GPU; the caller knows it is there)
+__device__ __forceinline__ int shared_index(const pf_problem& P, int dof) {
+  int lo = 0, hi = P.n_shared - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (P.shared_dofs[mid] < dof) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
 // ---- residual, losses, dL/df_int --------------------------------------------------------------
+// iface (multi-GPU, may be NULL): the all-reduced f_int of the shared dofs.  With it the shared dofs get
+// their complete f_int here and the OWNER rank counts them in the sums; without it they are left to
+// pf_iface_fix_residual (building-block path).
 template <int DIM>
 __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_residual(pf_problem P, float* f_int_out,
-                                                                    int compute_loss) {
+                                                                    int compute_loss,
+                                                                    const float* __restrict__ iface) {
   if (P.state->done) return;
   __shared__ float red[16];
   const pf_mesh& M = P.mesh;
@@ -55,12 +77,15 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_residual(pf_problem P,
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
       const int dof = node * DIM + c;
+      const unsigned fl = M.dof_flags[dof];
+      bool mine = !(fl & PF_DOF_SHARED);
+      if (iface && (fl & PF_DOF_SHARED)) {
+        f[c] = iface[P.shared_slot[shared_index(P, dof)]];
+        mine = !(fl & PF_DOF_GHOST);
+      }
       if (f_int_out) f_int_out[dof] = f[c];
       if (!compute_loss) continue;
-      const unsigned fl = M.dof_flags[dof];
       float gf = 0.f;
-      // shared dofs (multi-GPU): f_int is still partial here; pf_iface_fix_residual redoes them
-      const bool mine = !(fl & PF_DOF_SHARED);
       if (!(fl & PF_DOF_FIXED)) {
         const float r = f[c] - P.lam * M.f_ext[dof];  // solver.py:267-269
         if (mine) sum_r2 += r * r;
@@ -93,8 +118,11 @@ __global__ __launch_bounds__(256) void k_elem_adjoint(pf_problem P) {
 }
 
 // ---- dL/du (+ Adam on u, BC clamp, ||u_free||^2) ------------------------------------------------
+// skip_shared (multi-GPU): shared dofs are left alone; their gradient is completed by the second
+// all-reduce and pf_shard_update_shared steps them.
 template <int DIM, bool FUSE_ADAM>
-__global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P) {
+__global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P, int skip_shared) {
+  PF_NO_CONTRACT
   if (P.state->done) return;
   __shared__ float red[16];
   const pf_mesh& M = P.mesh;
@@ -111,6 +139,7 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P) {
     for (int c = 0; c < DIM; ++c) {
       const int dof = node * DIM + c;
       const unsigned fl = M.dof_flags[dof];
+      if (skip_shared && (fl & PF_DOF_SHARED)) continue;
       float gu = g[c];
       float uo = P.u[dof];
       if (P.use_data && (fl & PF_DOF_MEASURED)) {
@@ -171,6 +200,7 @@ __global__ __launch_bounds__(256) void k_theta_stage1(pf_problem P, int nb_rows)
 // stage 2 (device function, one block): PF_RG partial rows -> grad_theta[q] (+ Adam, refreshed padded
 // image).  new_theta (LDS, n_theta_active floats) receives the updated parameters when non-null.
 __device__ __forceinline__ void theta_stage2(const pf_problem& P, int fuse_adam, float* new_theta) {
+  PF_NO_CONTRACT
   const float* __restrict__ p2 = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total;
   const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
   const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
@@ -337,6 +367,167 @@ __global__ __launch_bounds__(256) void k_iface_fix_residual(pf_problem P, const 
   }
 }
 
+// ---- phase A: the nets on the interface elements + partial f_int of the shared dofs -----------------
+// One property of one element with plain fmaf chains in exactly the order of the MFMA kernels
+// (pf_net44.hip: bias first, inputs ascending, four output chains; an f32 MFMA is a chain of fmaf), so the
+// value is bit for bit the one the full forward pass writes for the same element a moment later.
+__device__ float eval_net_scalar(const pf_problem& P, int which, int e) {
+  const pf_net& net = P.net[which];
+  if (!net.enabled) return net.scale;
+  const int hp = ((net.width + 3) / 4) * 4, L = net.n_hidden, in = net.in_dim;
+  const float* __restrict__ w = P.theta_pad + net.pad_off;
+  float x[4] = {P.lam, 0.f, 0.f, 0.f};
+  for (int c = 1; c < in; ++c) x[c] = P.mesh.ecent[(size_t)e * (in - 1) + (c - 1)];
+  float ha[32], hb[32];
+  for (int j = 0; j < hp; ++j) {
+    float acc = fmaf(w[j * 4 + in], 1.0f, 0.f);
+    for (int c = 0; c < in; ++c) acc = fmaf(w[j * 4 + c], x[c], acc);
+    ha[j] = pf_tanh(acc);
+  }
+  float* hin = ha;
+  float* hout = hb;
+  for (int l = 2; l <= L; ++l) {
+    const float* __restrict__ wl = w + pf_pad_wh(hp, l);
+    for (int j = 0; j < hp; ++j) {
+      float acc = fmaf(wl[j * (hp + 4) + hp], 1.0f, 0.f);
+      for (int k = 0; k < hp; ++k) acc = fmaf(wl[j * (hp + 4) + k], hin[k], acc);
+      hout[j] = pf_tanh(acc);
+    }
+    float* t = hin; hin = hout; hout = t;
+  }
+  const float* __restrict__ wo = w + pf_pad_wo(hp, L);
+  float ao[4] = {wo[hp], 0.f, 0.f, 0.f};
+  for (int k = 0; k < hp; ++k) ao[(k + 1) % 4] = fmaf(wo[k], hin[k], ao[(k + 1) % 4]);
+  const float z = (ao[0] + ao[1]) + (ao[2] + ao[3]);
+  return (net.positive ? pf_softplus(z) : z) * net.scale;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_iface_forward(pf_problem P, float* __restrict__ iface) {
+  if (P.state->done) return;
+  __shared__ float sE[PF_MAX_IFACE_ELEMS], sA[PF_MAX_IFACE_ELEMS];
+  const pf_mesh& M = P.mesh;
+  for (int k = threadIdx.x; k < P.n_iface; k += blockDim.x) iface[k] = 0.f;
+  for (int i = threadIdx.x; i < P.n_iface_elems; i += blockDim.x) {
+    const int e = P.iface_elems[i];
+    sE[i] = eval_net_scalar(P, 0, e);
+    sA[i] = eval_net_scalar(P, 1, e);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < P.n_shared; k += blockDim.x) {
+    const int dof = P.shared_dofs[k], node = dof / DIM, c = dof % DIM;
+    float acc[2] = {0.f, 0.f};
+    for (int idx = M.adj_ptr[node]; idx < M.adj_ptr[node + 1]; ++idx) {   // ascending element id, like gather_kv
+      const int code = M.adj[idx];
+      const int e = code >> 1, end = code & 1;
+      int lo = 0, hi = P.n_iface_elems - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (P.iface_elems[mid] < e) lo = mid + 1; else hi = mid;
+      }
+      const int2 nn = reinterpret_cast<const int2*>(M.conn)[e];
+      const ElemGeo g = load_geo(M.egeo, e);
+      const float s = (sE[lo] * sA[lo]) / g.l0;
+      float vi[2], vj[2], fe[2];
+      load_vec<DIM>(P.u, nn.x, vi);
+      load_vec<DIM>(P.u, nn.y, vj);
+      ke_rows_times<DIM>(g, s, end, vi, vj, fe, P.fe_mode);
+#pragma unroll
+      for (int q = 0; q < DIM; ++q) acc[q] += fe[q];
+    }
+    iface[P.shared_slot[k]] = acc[c];
+  }
+}
+
+// ---- phase C tail: theta stage 2 (no Adam) into grad_theta (inside buf2), partial grad_u of the shared
+// dofs, local loss sums: buf2 = [iface grad_u (n_iface) | grad_theta (n_theta_active) | r2, d2, 0] ------------
+template <int DIM>
+__global__ __launch_bounds__(1024) void k_shard_pack(pf_problem P, int nb_node, float* __restrict__ buf2) {
+  if (P.state->done) return;
+  __shared__ double dred[16];
+  const pf_mesh& M = P.mesh;
+  if (P.n_theta_active > 0) theta_stage2(P, 0, nullptr);
+  for (int k = threadIdx.x; k < P.n_iface; k += blockDim.x) buf2[k] = 0.f;
+  __syncthreads();
+  const float dcoef = P.n_meas_f > 0.f ? P.alpha_data / P.n_meas_f : 0.f;
+  for (int k = threadIdx.x; k < P.n_shared; k += blockDim.x) {
+    const int dof = P.shared_dofs[k], node = dof / DIM, c = dof % DIM;
+    float g[2];
+    gather_kv<DIM>(P, P.g_f, node, g);
+    float gu = g[c];
+    if (P.use_data && (M.dof_flags[dof] & PF_DOF_MEASURED)) {   // only the owner carries the flag
+      const float d = M.meas_val[dof] - P.u[dof];
+      gu += -(dcoef * (2.f * d));
+    }
+    buf2[P.shared_slot[k]] = gu;
+  }
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < nb_node; i += blockDim.x) {
+    a += (double)P.partials[PF_PART_R2 + i];
+    b += (double)P.partials[PF_PART_D2 + i];
+  }
+  const double ta = pf_block_sum_d(a, dred), tb = pf_block_sum_d(b, dred);
+  if (threadIdx.x == 0) {
+    float* tail = buf2 + P.n_iface + P.n_theta_active;
+    tail[0] = (float)ta; tail[1] = (float)tb; tail[2] = 0.f;
+  }
+}
+
+// ---- phase E: Adam(theta) from the reduced gradient, Adam(u) of the shared dofs, sum u_free^2 -----------
+__global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node, const float* __restrict__ buf2,
+                                                       float* __restrict__ sums3) {
+  PF_NO_CONTRACT
+  if (P.state->done) return;   // sums3 keeps the previous (final) value: finalize ignores it once done
+  __shared__ double dred[16];
+  const pf_mesh& M = P.mesh;
+  const float bc2s = P.state->bc2_sqrt;
+  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
+  const float eps = (float)P.eps;
+  {
+    const float step_size = P.state->step_size_t;
+    for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
+      const float g = P.grad_theta[q];
+      float m = P.m_t[q], v = P.v_t[q], th = P.theta[q];
+      m = m + b1w * (g - m);
+      v = v * b2;
+      v = v + (b2w * g) * g;
+      const float denom = sqrtf(v) / bc2s + eps;
+      th = th + (-step_size) * (m / denom);
+      P.m_t[q] = m;
+      P.v_t[q] = v;
+      P.theta[q] = th;
+      P.theta_pad[P.pad_index[q]] = th;
+    }
+  }
+  double c = 0.0;
+  {
+    const float step_size = P.state->step_size_u;
+    for (int k = threadIdx.x; k < P.n_shared; k += blockDim.x) {
+      const int dof = P.shared_dofs[k];
+      const unsigned fl = M.dof_flags[dof];
+      float uo = P.u[dof];
+      if (fl & PF_DOF_FIXED) {
+        if (uo != 0.f) P.u[dof] = 0.f;
+        continue;
+      }
+      const float gu = buf2[P.shared_slot[k]];
+      float m = P.m_u[dof], v = P.v_u[dof];
+      m = m + b1w * (gu - m);
+      v = v * b2;
+      v = v + (b2w * gu) * gu;
+      const float denom = sqrtf(v) / bc2s + eps;
+      uo = uo + (-step_size) * (m / denom);
+      if (!(fl & PF_DOF_GHOST)) c += (double)(uo * uo);
+      P.m_u[dof] = m;
+      P.v_u[dof] = v;
+      P.u[dof] = uo;
+    }
+  }
+  for (int i = threadIdx.x; i < nb_node; i += blockDim.x) c += (double)P.partials[PF_PART_U2 + i];
+  const double tc = pf_block_sum_d(c, dred);
+  if (threadIdx.x == 0) { sums3[0] = 0.f; sums3[1] = 0.f; sums3[2] = (float)tc; }
+}
+
 __global__ __launch_bounds__(1024) void k_local_sums(pf_problem P, int nb, float* __restrict__ sums3) {
   __shared__ double dred[16];
   double a = 0.0, b = 0.0, c = 0.0;
@@ -352,6 +543,7 @@ __global__ __launch_bounds__(1024) void k_local_sums(pf_problem P, int nb, float
 
 // Adam on u from a given gradient + clamp + ||u_free||^2 partials (owned dofs only)
 __global__ __launch_bounds__(PF_NODE_THREADS) void k_adam_u(pf_problem P) {
+  PF_NO_CONTRACT
   if (P.state->done) return;
   __shared__ float red[16];
   const pf_mesh& M = P.mesh;
@@ -383,6 +575,7 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_adam_u(pf_problem P) {
 }
 
 __global__ __launch_bounds__(1024) void k_adam_theta(pf_problem P) {
+  PF_NO_CONTRACT
   if (P.state->done) return;
   const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
   const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
@@ -421,6 +614,7 @@ __global__ void k_reset(pf_problem P) {
 // ---- generic Adam ------------------------------------------------------------------------------
 __global__ void k_adam(float* p, const float* g, float* m, float* v, int n, float step_size,
                        float bc2s, float b1w, float b2, float b2w, float eps) {
+  PF_NO_CONTRACT
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i];
@@ -489,12 +683,24 @@ __global__ void k_dense_k(pf_problem P, float* K) {
 // ---- host launchers (called from pf_api.hip) ---------------------------------------------------
 #define PF_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP)
 
-int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s) {
-  const int nb = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks);
+int pf_node_blocks(int n_nodes) {
+  // measured at 10^6 nodes (MI355X): 2048 blocks (8 waves per SIMD, ~2 nodes per thread) beat both 1024
+  // and one-node-per-thread 4096 by 2-3 us per node kernel.  PF_NODE_BLOCKS: experiment knob.
+  static const int cap = getenv("PF_NODE_BLOCKS") ? atoi(getenv("PF_NODE_BLOCKS")) : 2048;
+  int nb = (n_nodes + PF_NODE_THREADS - 1) / PF_NODE_THREADS;
+  if (nb > cap) nb = cap;
+  if (nb > PF_MAX_NODE_BLOCKS) nb = PF_MAX_NODE_BLOCKS;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+
+int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s,
+                            const float* iface) {
+  const int nb = pf_node_blocks(p->mesh.n_nodes);
   if (p->mesh.dim == 2)
-    hipLaunchKernelGGL(k_node_residual<2>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss);
+    hipLaunchKernelGGL(k_node_residual<2>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss, iface);
   else
-    hipLaunchKernelGGL(k_node_residual<1>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss);
+    hipLaunchKernelGGL(k_node_residual<1>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss, iface);
   return PF_CHECK_LAUNCH();
 }
 
@@ -507,15 +713,15 @@ int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s) {
   return PF_CHECK_LAUNCH();
 }
 
-int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s) {
-  const int nb = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks);
+int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared) {
+  const int nb = pf_node_blocks(p->mesh.n_nodes);
   const dim3 g(nb), b(PF_NODE_THREADS);
   if (p->mesh.dim == 2) {
-    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<2, true>), g, b, 0, s, *p);
-    else hipLaunchKernelGGL((k_node_gradu<2, false>), g, b, 0, s, *p);
+    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<2, true>), g, b, 0, s, *p, skip_shared);
+    else hipLaunchKernelGGL((k_node_gradu<2, false>), g, b, 0, s, *p, skip_shared);
   } else {
-    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<1, true>), g, b, 0, s, *p);
-    else hipLaunchKernelGGL((k_node_gradu<1, false>), g, b, 0, s, *p);
+    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<1, true>), g, b, 0, s, *p, skip_shared);
+    else hipLaunchKernelGGL((k_node_gradu<1, false>), g, b, 0, s, *p, skip_shared);
   }
   return PF_CHECK_LAUNCH();
 }
@@ -549,7 +755,7 @@ int pf_launch_pack_theta(const pf_problem* p, hipStream_t s) {
 
 // with_theta: also run theta stage 2 (+Adam in mode 0) inside the finalize block
 int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s) {
-  const int nb_node = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks);
+  const int nb_node = pf_node_blocks(p->mesh.n_nodes);
   const int wt = with_theta && p->n_theta_active > 0;
   const size_t lds = wt ? (size_t)p->n_theta_active * sizeof(float) : 0;
   if (lds > 60000) {
@@ -604,17 +810,33 @@ int pf_launch_iface_unpack(const pf_problem* p, const float* iface, float* vec, 
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_iface_fix_residual(const pf_problem* p, const float* iface, hipStream_t s) {
-  const int slot = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks);
+  const int slot = pf_node_blocks(p->mesh.n_nodes);
   hipLaunchKernelGGL(k_iface_fix_residual, dim3(1), dim3(256), 0, s, *p, iface, slot);
   return PF_CHECK_LAUNCH();
 }
+int pf_launch_iface_forward(const pf_problem* p, float* iface, hipStream_t s) {
+  if (p->mesh.dim == 2) hipLaunchKernelGGL(k_iface_forward<2>, dim3(1), dim3(256), 0, s, *p, iface);
+  else hipLaunchKernelGGL(k_iface_forward<1>, dim3(1), dim3(256), 0, s, *p, iface);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_shard_pack(const pf_problem* p, float* buf2, hipStream_t s) {
+  const int nb = pf_node_blocks(p->mesh.n_nodes);
+  if (p->mesh.dim == 2) hipLaunchKernelGGL(k_shard_pack<2>, dim3(1), dim3(1024), 0, s, *p, nb, buf2);
+  else hipLaunchKernelGGL(k_shard_pack<1>, dim3(1), dim3(1024), 0, s, *p, nb, buf2);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* sums3, hipStream_t s) {
+  const int nb = pf_node_blocks(p->mesh.n_nodes);
+  hipLaunchKernelGGL(k_shard_update, dim3(1), dim3(1024), 0, s, *p, nb, buf2, sums3);
+  return PF_CHECK_LAUNCH();
+}
 int pf_launch_local_sums(const pf_problem* p, float* sums3, hipStream_t s) {
-  const int nb = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks) + (p->n_shared > 0 ? 1 : 0);
+  const int nb = pf_node_blocks(p->mesh.n_nodes) + (p->n_shared > 0 ? 1 : 0);
   hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(1024), 0, s, *p, nb, sums3);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_adam_u(const pf_problem* p, hipStream_t s) {
-  const int nb = pf_node_blocks(p->mesh.n_nodes, p->n_part_blocks);
+  const int nb = pf_node_blocks(p->mesh.n_nodes);
   hipLaunchKernelGGL(k_adam_u, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p);
   return PF_CHECK_LAUNCH();
 }

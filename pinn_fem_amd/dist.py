@@ -6,9 +6,17 @@ build's answer to BASELINE.json's "shard elements across the 8 GPUs of one node"
 Partition: contiguous element ranges.  A node whose elements live on several ranks is SHARED; every
 sharing rank keeps a copy of its u and Adam state, and the lowest sharing rank OWNS it (counts it in
 global sums, adds its data-loss term).  Per GD iteration there are TWO small all-reduces, the floor
-for this partition (one exchange before the residual, one after the backward):
-  (1) [sum u_free^2 of the PREVIOUS iteration | interface vector of partial f_int]
-  (2) [interface grad_u | grad_theta | sum r^2, sum d^2]
+for this partition (one exchange before the residual, one after the backward), in stream order:
+  (1) [sum u_free^2 of the PREVIOUS iteration | partial f_int of the shared dofs]
+      The few elements touching a shared node are evaluated first (phase A, one tiny kernel with the
+      arithmetic of the full net kernels, bit for bit), so the exchange does not wait for the forward
+      pass over all elements (phase B).
+  (2) [partial grad_u of the shared dofs | grad_theta | sum r^2, sum d^2]
+      after the backward (phase C) and grad_u + Adam(u) of every dof that is NOT shared (phase D);
+      Adam(theta) and the shared dofs follow (phase E).
+Measured on MI355X: hiding the two collectives on a second stream costs more than it saves (cross-stream
+event pairs between eager launches ~9 us each on this runtime; the vectors are <= 4 kB, i.e. pure
+latency), and so does one hipGraph replay per iteration; everything runs in stream order on one stream.
 The u-norm is a monitor only, so it rides on the next iteration's first collective and the
 bookkeeping kernel of iteration t (history row, stop test, next Adam scalars) runs right after that
 collective, before anything of iteration t+1 that could change state; a chunk ends with one flush
@@ -52,6 +60,7 @@ class Shard:
     ghost_mask: np.ndarray       # bool per local dof: shared and owned by a lower rank
     n_iface: int
     dim: int
+    iface_elems: Optional[np.ndarray] = None   # local element ids touching a shared node (ascending)
 
 
 def element_ranges(n_elems: int, world: int) -> List[Tuple[int, int]]:
@@ -96,10 +105,12 @@ def partition_mesh(elements: np.ndarray, n_nodes: int, dim: int, rank: int, worl
     ghost_nodes = local_idx[not_owner]
     if ghost_nodes.size:
         ghost[(ghost_nodes[:, None] * dim + comp[None, :]).reshape(-1)] = True
+    touches = np.isin(loc, my_shared_nodes).any(axis=1) if loc.size else np.zeros(0, dtype=bool)
     return Shard(rank=rank, world=world, elem_lo=lo, elem_hi=hi, nodes_global=nodes_global,
                  elements_local=elements_local, shared_dofs=shared_dofs.astype(np.int32),
                  shared_slot=shared_slot.astype(np.int32), ghost_mask=ghost,
-                 n_iface=int(len(shared_nodes) * dim), dim=dim)
+                 n_iface=int(len(shared_nodes) * dim), dim=dim,
+                 iface_elems=np.flatnonzero(touches).astype(np.int32))
 
 
 def shard_host_plan(shard: Shard, nodes, loads, fixed_dofs, measured_disp, measured_dofs,
@@ -139,24 +150,25 @@ def shard_host_plan(shard: Shard, nodes, loads, fixed_dofs, measured_disp, measu
 # ---------------------------------------------------------------------------------------------------
 class ShardBackend:
     """What the driver needs from one rank's local problem.  All tensors live on `device`.
-    Buffers: buf1 = [3 floats: -, -, sum u_free^2 | interface f_int (n_iface)],
-             buf2 = [interface grad_u (n_iface) | grad_theta (n_theta_active) | sum r^2, sum d^2, -]."""
+    Buffers: buf1 = [3 floats: 0, 0, sum u_free^2 | partial f_int of the shared dofs (n_iface)],
+             buf2 = [partial grad_u of the shared dofs (n_iface) | grad_theta (n_theta_active) | sum r^2, sum d^2, 0].
+    Phases of one iteration (stream-ordered; see the module docstring):"""
     device: torch.device
     n_iface: int
     n_theta_active: int
 
-    def forward_residual(self): ...            # nets forward + local partial f_int (+ local losses)
-    def pack_f(self, iface: torch.Tensor): ...            # iface[slot] = partial f_int (else 0)
-    def fix_residual(self, iface: torch.Tensor): ...      # full f_int on shared dofs -> residual
-    def backward(self, buf2: torch.Tensor): ...           # -> [iface grad_u | grad_theta | r2, d2, -]
-    def update(self, buf2: torch.Tensor, sums3: torch.Tensor): ...  # Adam(u), Adam(theta); sums3[2]=local sum u^2
+    def iface_forward(self, iface: torch.Tensor): ...     # A: interface elements -> iface[slot] (else 0)
+    def forward(self): ...                                # B: nets on all elements
+    def backward(self, iface: torch.Tensor, buf2: torch.Tensor): ...   # C: residual (reduced f_int), backward, pack buf2
+    def update_interior(self): ...                        # D: grad_u + Adam(u) of the dofs that are not shared
+    def update_shared(self, buf2: torch.Tensor, sums3: torch.Tensor): ...  # E: Adam(theta), shared dofs; sums3[2]
     def finalize(self, r2d2: torch.Tensor, u2: torch.Tensor): ...
 
 
 def _all_reduce(t: torch.Tensor, group=None):
-    """Sum over ranks, in place.  RCCL reduces device tensors directly; with a gloo group (CPU tests,
-    or several ranks sharing one GPU in the single-GPU rehearsal) device tensors are staged through
-    the host."""
+    """Sum over ranks, in place, ordered on the current stream.  RCCL reduces device tensors directly;
+    with a gloo group (CPU tests, or several ranks sharing one GPU in the single-GPU rehearsal) device
+    tensors are staged through the host."""
     if t.is_cuda and dist.get_backend(group) == "gloo":
         h = t.cpu()
         dist.all_reduce(h, group=group)
@@ -165,13 +177,77 @@ def _all_reduce(t: torch.Tensor, group=None):
         dist.all_reduce(t, group=group)
 
 
+# own RCCL communicator for the C iteration driver (pf_comm.hip): one per process and group
+_RCCL_COMMS = {}
+
+
+def _librccl_path() -> str:
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return cand if os.path.exists(cand) else "librccl.so"
+
+
+def rccl_comm(backend, group=None):
+    """The C driver's communicator, or None when the Python driver has to be used: not the HIP
+    backend, not an RCCL ("nccl") process group, PINNFEM_SHARD_DRIVER=python, or creation failed on any
+    rank (decided collectively, so every rank takes the same path)."""
+    if not isinstance(backend, HipShardBackend) or not dist.is_initialized():
+        return None
+    if dist.get_backend(group) != "nccl" or os.environ.get("PINNFEM_SHARD_DRIVER", "c") == "python":
+        return None
+    key = id(group)
+    if key in _RCCL_COMMS:
+        return _RCCL_COMMS[key]
+    import ctypes as C
+    lib, dev = backend.eng.lib, backend.device
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    path = _librccl_path().encode()
+    idbuf = (C.c_char * _capi.PF_COMM_ID_BYTES)()
+    ok = 1
+    if rank == 0 and lib.pf_comm_unique_id(path, idbuf) != 0:
+        ok = 0
+    t = torch.zeros(_capi.PF_COMM_ID_BYTES + 1, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t[:-1] = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).to(dev)
+        t[-1] = ok
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    host = t.cpu().numpy()
+    comm = C.c_void_p()
+    if int(host[-1]) == 1:
+        with torch.cuda.device(dev):
+            rc = lib.pf_comm_create(path, host[:-1].tobytes(), rank, world, C.byref(comm))
+        ok = 1 if rc == 0 else 0
+    else:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) != 1:
+        if comm.value:
+            lib.pf_comm_destroy(comm)
+        if rank == 0 and os.environ.get("PINNFEM_QUIET", "0") != "1":
+            print("pinn_fem_amd: own RCCL communicator unavailable (%s); using the torch.distributed driver"
+                  % lib.pf_last_error().decode(errors="replace"), flush=True)
+        comm = None
+    _RCCL_COMMS[key] = comm
+    return comm
+
+
 def run_iterations(backend: ShardBackend, n_iter: int, group=None,
                    bufs: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """n_iter GD iterations with the two collectives per iteration of the module docstring (+ one
-    flush at the end, so the device state is final when this returns)."""
+    flush at the end, so the device state is final when this returns).  On an RCCL process group the
+    HIP backend's iterations are issued by the C driver (pf_shard_iterations: kernels and ncclAllReduce
+    from one C loop, no Python between them); everything else goes through the Python schedule below."""
     if bufs is None:
         bufs = getattr(backend, "bufs", None) or make_buffers(backend)
     eng = getattr(backend, "eng", None)
+    comm = rccl_comm(backend, group) if n_iter > 0 else None
+    if comm is not None and backend.early_iface:
+        g0, g1 = backend.graphs()
+        with eng.on_stream():
+            _capi.check(eng.lib.pf_shard_iterations(eng._ref(), comm, int(n_iter), bufs[0].data_ptr(),
+                                                    bufs[1].data_ptr(), g0, g1, eng._stream()),
+                        "pf_shard_iterations")
+        return bufs
     ctx = eng.on_stream() if eng is not None else contextlib.nullcontext()
     with ctx:   # kernels and collectives on one stream (the engine's)
         _run_iterations(backend, n_iter, group, bufs[0], bufs[1])
@@ -183,15 +259,15 @@ def _run_iterations(backend, n_iter, group, buf1, buf2):
     r2d2 = buf2[ni + nt:ni + nt + 2]
     pending = False
     for _ in range(n_iter):
-        backend.forward_residual()
-        backend.pack_f(buf1[3:])
+        backend.iface_forward(buf1[3:])
         _all_reduce(buf1, group)                 # (1) + the previous iteration's sum u^2 in buf1[2]
+        backend.forward()
         if pending:
             backend.finalize(r2d2, buf1[2:3])    # bookkeeping of the previous iteration
-        backend.fix_residual(buf1[3:])
-        backend.backward(buf2)
+        backend.backward(buf1[3:], buf2)
+        backend.update_interior()
         _all_reduce(buf2, group)                 # (2)
-        backend.update(buf2, buf1[:3])
+        backend.update_shared(buf2, buf1[:3])
         pending = True
     if pending:
         _all_reduce(buf1[:3], group)             # flush: the last iteration's sum u^2
@@ -215,46 +291,62 @@ class HipShardBackend(ShardBackend):
                  device=None, wg_mode=None, fe_mode=None):
         from .engine import HipEngine
         self.shard = shard
+        ie = shard.iface_elems if shard.iface_elems is not None else np.zeros(0, dtype=np.int32)
+        # phase A needs the interface elements in one block's LDS; a very long interface (a mesh cut
+        # across thousands of elements) falls back to "full forward, then gather": correct, no overlap
+        self.early_iface = len(ie) <= _capi.PF_MAX_IFACE_ELEMS
         self.eng = HipEngine(local_model, device=device, host_plan=host_plan, wg_mode=wg_mode,
-                             fe_mode=fe_mode, n_part_blocks=_capi.PF_MAX_BLOCKS - 1,
-                             iface=(shard.shared_dofs, shard.shared_slot, shard.n_iface))
+                             fe_mode=fe_mode,
+                             iface=(shard.shared_dofs, shard.shared_slot, shard.n_iface,
+                                    ie if self.early_iface else None))
         self.eng.has_measurements = has_measurements
         self.device = self.eng.device
         self.n_iface = shard.n_iface
         self.n_theta_active = self.eng.n_theta_active
-        self.fbuf = torch.zeros(host_plan.n_dofs, dtype=torch.float32, device=self.device)
+        self.fbuf = None if self.early_iface else torch.zeros(host_plan.n_dofs, dtype=torch.float32,
+                                                               device=self.device)
         self.bufs = make_buffers(self)           # (buf1, buf2): fixed addresses, baked into the graphs
-        self._graphs = None
-        self.use_graphs = os.environ.get("PINNFEM_GRAPH", "1") != "0"
+        self._graphs = None                      # C driver only
 
     # -- solve_gd-level control ---------------------------------------------------------------------
     def begin(self, u_initial_local, lam, config, want_history=True):
         self._drop_graphs()
         self.eng.begin(u_initial_local, lam, config, want_history=want_history)
-        # gradients land where the collectives read them: grad_theta is reduced straight into buf2
-        self.eng.P.grad_u = self.eng.grad_u.data_ptr()
+        # grad_theta is reduced straight into buf2, where the second collective reads it
         self.eng.P.grad_theta = self.bufs[1].data_ptr() + 4 * self.n_iface
+        self.bufs[0].zero_()
 
     def _drop_graphs(self):
         if self._graphs:
             for g in self._graphs:
-                self.eng.lib.pf_graph_destroy(g)
+                if g:
+                    self.eng.lib.pf_graph_destroy(g)
         self._graphs = None
 
-    def _phase(self, k, eager):
-        """Phase k (0..2) of the iteration: replay its hipGraph (captured on first use) or launch eagerly."""
-        e = self.eng
-        if not self.use_graphs:
-            return eager()
+    def graphs(self):
+        """The two hipGraphs of pf_shard_graph_create (phases B..D without / with the previous
+        iteration's bookkeeping) for the C driver.  OFF by default: one graph replay per iteration
+        measured slower than the same kernels launched one by one (0.271 vs 0.226 ms per iteration at 10^6
+        elements, world_size 1, MI355X) — the replay's fixed cost is not amortised over one iteration the
+        way the single-GPU path amortises it over ten.  PINNFEM_SHARD_GRAPH=1 turns it on."""
+        if os.environ.get("PINNFEM_SHARD_GRAPH", "0") != "1":
+            return None, None
         if self._graphs is None:
             import ctypes as C
-            arr = (C.c_void_p * 3)()
+            e = self.eng
             buf1, buf2 = self.bufs
-            _capi.check(e.lib.pf_shard_graphs_create(e._ref(), self.fbuf.data_ptr(), buf1.data_ptr() + 12,
-                                                     buf2.data_ptr(), buf1.data_ptr(), e._stream(), arr),
-                        "pf_shard_graphs_create")
-            self._graphs = [C.c_void_p(arr[i]) for i in range(3)]
-        _capi.check(e.lib.pf_graph_launch(self._graphs[k], e._stream()), "pf_graph_launch")
+            out = []
+            with e.on_stream():
+                for with_fin in (0, 1):
+                    g = C.c_void_p()
+                    _capi.check(e.lib.pf_shard_graph_create(e._ref(), buf1.data_ptr(), buf2.data_ptr(), with_fin,
+                                                            e._stream(), C.byref(g)), "pf_shard_graph_create")
+                    out.append(g)
+            self._graphs = out
+        return self._graphs[0], self._graphs[1]
+
+    def _phase(self, k, eager):
+        return eager()
 
     def state(self):
         return self.eng.state()
@@ -262,7 +354,7 @@ class HipShardBackend(ShardBackend):
     def history(self, n):
         return self.eng.history(n)
 
-    # -- ShardBackend: one C call (or one graph replay) per phase, pf_finalize_from for the bookkeeping ----
+    # -- ShardBackend (Python driver: gloo tests, single-GPU rehearsal, fallback): one C call per phase ----
     def _check_bufs(self, *tensors):
         buf1, buf2 = self.bufs
         lo1, hi1 = buf1.data_ptr(), buf1.data_ptr() + 4 * buf1.numel()
@@ -272,28 +364,46 @@ class HipShardBackend(ShardBackend):
             if t.numel() and not (lo1 <= p < hi1 or lo2 <= p < hi2):
                 raise ValueError("HipShardBackend works on its own collective buffers (backend.bufs)")
 
-    def forward_residual(self):
-        pass                                   # done together with the interface pack in pack_f()
+    def _iface_ptr(self, iface):
+        # an empty view (world_size 1: no interface) has no address of its own
+        return iface.data_ptr() if iface.numel() else self.bufs[0].data_ptr() + 12
 
-    def pack_f(self, iface):
+    def iface_forward(self, iface):
         e = self.eng
         self._check_bufs(iface)
+        if not self.early_iface:
+            # fallback: full forward, partial f_int of every dof, pack the shared ones
+            s = e._stream()
+            _capi.check(e.lib.pf_shard_forward(e._ref(), s), "pf_shard_forward")
+            _capi.check(e.lib.pf_internal_force(e._ref(), e.u.data_ptr(), self.fbuf.data_ptr(), s), "pf_internal_force")
+            _capi.check(e.lib.pf_iface_pack(e._ref(), self.fbuf.data_ptr(), iface.data_ptr(), s), "pf_iface_pack")
+            return
         self._phase(0, lambda: _capi.check(
-            e.lib.pf_shard_phase1(e._ref(), self.fbuf.data_ptr(), iface.data_ptr(), e._stream()), "pf_shard_phase1"))
+            e.lib.pf_shard_iface_forward(e._ref(), self._iface_ptr(iface), e._stream()), "pf_shard_iface_forward"))
 
-    def fix_residual(self, iface):
-        self._if1_ptr = iface.data_ptr()       # consumed at the start of phase 2
-
-    def backward(self, buf2):
+    def forward(self):
         e = self.eng
-        self._check_bufs(buf2)
-        self._phase(1, lambda: _capi.check(
-            e.lib.pf_shard_phase2(e._ref(), self._if1_ptr, buf2.data_ptr(), e._stream()), "pf_shard_phase2"))
+        if not self.early_iface:
+            return
+        self._phase(1, lambda: _capi.check(e.lib.pf_shard_forward(e._ref(), e._stream()), "pf_shard_forward"))
 
-    def update(self, buf2, sums3):
+    def backward(self, iface, buf2):
         e = self.eng
+        self._check_bufs(iface, buf2)
         self._phase(2, lambda: _capi.check(
-            e.lib.pf_shard_phase3(e._ref(), buf2.data_ptr(), sums3.data_ptr(), e._stream()), "pf_shard_phase3"))
+            e.lib.pf_shard_backward(e._ref(), self._iface_ptr(iface), buf2.data_ptr(), e._stream()), "pf_shard_backward"))
+
+    def update_interior(self):
+        e = self.eng
+        self._phase(3, lambda: _capi.check(
+            e.lib.pf_shard_update_interior(e._ref(), e._stream()), "pf_shard_update_interior"))
+
+    def update_shared(self, buf2, sums3):
+        e = self.eng
+        self._check_bufs(buf2, sums3)
+        self._phase(4, lambda: _capi.check(
+            e.lib.pf_shard_update_shared(e._ref(), buf2.data_ptr(), sums3.data_ptr(), e._stream()),
+            "pf_shard_update_shared"))
 
     def finalize(self, r2d2, u2):
         e = self.eng
@@ -382,10 +492,12 @@ class ShardedChainEngine:
         if rank < world - 1:
             sd += [2 * n, 2 * n + 1]
             ss += [2 * rank, 2 * rank + 1]
+        ie = ([0] if rank > 0 else []) + ([n - 1] if rank < world - 1 else [])   # elements at the shared nodes
         shard = Shard(rank=rank, world=world, elem_lo=e0, elem_hi=e0 + n,
                       nodes_global=np.arange(e0, e0 + n + 1), elements_local=el,
                       shared_dofs=np.array(sd, dtype=np.int32), shared_slot=np.array(ss, dtype=np.int32),
-                      ghost_mask=ghost, n_iface=2 * (world - 1), dim=2)
+                      ghost_mask=ghost, n_iface=2 * (world - 1), dim=2,
+                      iface_elems=np.array(sorted(set(ie)), dtype=np.int32))
         # measurements ux_i = x_i, uy_i = 0 at every global node >= 1 (owner adds the shared ones)
         k = np.arange(n + 1)
         keep = (k + e0 >= 1) & ~ghost[0::2]

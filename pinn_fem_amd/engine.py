@@ -59,10 +59,14 @@ class HipEngine:
         self.adj_ptr, self.adj = t(hp.adj_ptr), t(hp.adj)
         self.f_ext, self.dof_flags, self.meas_val = t(hp.f_ext), t(hp.dof_flags), t(hp.meas_val)
         self.has_measurements = measured_disp is not None and measured_dofs is not None
-        # multi-GPU shard interface: (shared_dofs int32[], shared_slot int32[], n_iface)
+        # multi-GPU shard interface: (shared_dofs int32[], shared_slot int32[], n_iface[, iface_elems int32[]])
+        self.iface_elems, self.n_iface_elems = None, 0
         if iface is not None:
             self.shared_dofs, self.shared_slot = t(np.asarray(iface[0], dtype=np.int32)), t(np.asarray(iface[1], dtype=np.int32))
             self.n_shared, self.n_iface = int(len(iface[0])), int(iface[2])
+            if len(iface) > 3 and iface[3] is not None and len(iface[3]):
+                self.iface_elems = t(np.asarray(iface[3], dtype=np.int32))
+                self.n_iface_elems = int(len(iface[3]))
         else:
             self.shared_dofs = self.shared_slot = None
             self.n_shared = self.n_iface = 0
@@ -135,7 +139,7 @@ class HipEngine:
         self.g_ea = torch.zeros(ne, **f32)
         self.grad_u = torch.zeros(nd, **f32)
         self.grad_theta = torch.zeros(max(self.n_theta, 1), **f32)
-        self.partials = torch.zeros(3 * _capi.PF_MAX_BLOCKS + (self.n_part_blocks + 16) * max(self.pad_total, 1), **f32)
+        self.partials = torch.zeros(3 * _capi.PF_NODE_SLOTS + (self.n_part_blocks + 16) * max(self.pad_total, 1), **f32)
         self.state_t = torch.zeros(C.sizeof(PfState) // 4, dtype=torch.int32, device=dev)
         self.hist = torch.zeros(1, **f32)
         self.hist_rows = 0
@@ -209,6 +213,8 @@ class HipEngine:
         P.shared_dofs = self.shared_dofs.data_ptr() if self.n_shared else None
         P.shared_slot = self.shared_slot.data_ptr() if self.n_shared else None
         P.n_shared, P.n_iface = self.n_shared, self.n_iface
+        P.iface_elems = self.iface_elems.data_ptr() if self.n_iface_elems else None
+        P.n_iface_elems = self.n_iface_elems
         self._configured = True
 
     def _ref(self):

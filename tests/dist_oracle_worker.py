@@ -1,7 +1,7 @@
 """World-size-N CPU worker (gloo) for tests/test_dist_gloo.py.
 
 Drives the PRODUCT's sharding logic (pinn_fem_amd.dist: partition_mesh, shard_host_plan,
-run_iterations and its three collectives) with an oracle-backed ShardBackend standing in for the HIP
+run_iterations and its collectives) with an oracle-backed ShardBackend standing in for the HIP
 kernels, and writes rank 0's view of the result.  Launched by torch.distributed.run.
 """
 import os
@@ -58,16 +58,21 @@ class OracleShardBackend(ShardBackend):
         self.m = float(hp.n_meas)
         self.history, self.done, self.converged, self.it = [], False, False, 0
 
-    def forward_residual(self):
+    # phase A (the product evaluates only the interface elements here; the values are the same)
+    def iface_forward(self, iface):
         s, *_ = orc.element_stiffness(self.pb, self.geo, self.lam)
         self.f_part = orc.internal_force(self.geo, s, self.u, self.hp.n_dofs)
-
-    def pack_f(self, iface):
         iface.zero_()
         iface[torch.from_numpy(self.shard.shared_slot.astype(np.int64))] = torch.from_numpy(
             self.f_part[self.shard.shared_dofs])
 
-    def fix_residual(self, iface):
+    def forward(self):        # phase B: nothing left to do for the CPU stand-in
+        pass
+
+    def update_interior(self):  # phase D: folded into update_shared
+        pass
+
+    def _fix_residual(self, iface):
         f = self.f_part.copy()
         f[self.shard.shared_dofs] = iface.numpy()[self.shard.shared_slot]
         r = (f - f32(self.lam) * self.hp.f_ext).astype(f32)
@@ -78,7 +83,8 @@ class OracleShardBackend(ShardBackend):
         self.d = d
         self.d2 = float(np.sum((d * d)[self.meas & self.owned], dtype=f32)) if self.use_data else 0.0
 
-    def backward(self, buf2):
+    def backward(self, iface, buf2):
+        self._fix_residual(iface)
         gu, gt = orc.vjp_internal_force(self.pb, self.geo, self.u, self.lam, self.g_f)
         if self.use_data:
             gd = (f32(self.cfg.alpha_data) / f32(self.m)) * (f32(2.0) * self.d)
@@ -93,7 +99,7 @@ class OracleShardBackend(ShardBackend):
             off += g.size
         b[self.n_iface + self.n_theta_active:self.n_iface + self.n_theta_active + 2] = (self.r2, self.d2)
 
-    def update(self, buf2, sums3):
+    def update_shared(self, buf2, sums3):
         b = buf2.numpy()
         self.grad_u[self.shard.shared_dofs] = b[self.shard.shared_slot]
         self.opt_u.update([self.u], [self.grad_u])

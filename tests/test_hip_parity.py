@@ -587,3 +587,21 @@ def test_cli_under_torchrun_two_ranks_one_gpu(tmp_path):
     assert sharded["converged"] == run["result"]["converged"]
     assert rel_err(sharded["displacements"], run["result"]["displacements"]) < 1e-5
     assert set(sharded) == set(run["result"])
+
+
+def test_sharded_c_driver_real_rccl_world1():
+    """The product's multi-GPU driver (pf_shard_iterations: kernels + ncclAllReduce from one C loop on an own
+    RCCL communicator) and the torch.distributed driver, both on a real RCCL process group of ONE rank (all
+    this box offers): bit-identical to the single-engine path after 40 iterations on a 20000-element chain."""
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1",
+               PINNFEM_QUIET="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_world1.py"), "20000", "30"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    got = json.loads(line)
+    assert got["iters"] == [40, 40]
+    assert got["rel_err_u"] == 0.0 and got["rel_err_theta"] == 0.0, got
