@@ -3,6 +3,9 @@ reference and against the oracle on the same inputs.  Tolerances are written nex
 everything is float32 arithmetic, so "parity" means agreement to float32 round-off of the quantity's
 own scale (the reference's own summation order is not specified by torch either).
 """
+import json
+import os
+
 import numpy as np
 import pytest
 import torch
