@@ -223,7 +223,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
                 tr = json.load(f)["kernels"]
-            key = {"net_backward_young": "k_net44_backward:young", "net_backward_area": "k_net44_backward:area",
+            key = {"net_backward_young": "k_net44_backward<2, 3, true>", "net_backward_area": "k_net44_backward<2, 3, false>",
                    "node_residual": "k_node_residual<2>", "node_gradu_adam": "k_node_gradu<2, true>"}.get(names[dom])
             if key in tr and n_local == 1_000_000 and args.workload == "ex4":
                 roof["traffic"] = tr[key]["hbm_bytes_corrected"]

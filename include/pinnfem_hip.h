@@ -291,6 +291,22 @@ int pf_comm_destroy(void* comm);
 int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf1, float* buf2,
                         void* graph_first, void* graph_next, void* stream);
 
+/* ---- classical Newton-Raphson support (pf_pcg.hip) ---------------------------
+ * The reference's solve_nr (FEM/python/fem/solver.py:408-512) solves K_ff du_f = rhs_f with
+ * np.linalg.solve on the dense float64 tangent of fem/assembly.py:16-75.  Here K is never formed:
+ * pf_kv_f64 applies it matrix-free in float64 and pf_pcg_* run a conjugate-gradient solve preconditioned
+ * with diag(K_ff) (Jacobi).  Vectors are double [n_dofs], fixed dofs carried as zeros; E and A come from
+ * p->prop_e / p->prop_a when the net is enabled, else from net.scale (scalar materials). */
+/* out = K v (all rows; zero_fixed != 0: rows of fixed dofs set to 0) */
+int pf_kv_f64(const pf_problem* p, const double* v, double* out, int zero_fixed, void* stream);
+/* doubles of workspace pf_pcg_* need */
+long long pf_pcg_workspace_count(const pf_problem* p);
+/* start a solve of K_ff x = b (entries of b on fixed dofs are ignored), x = 0; stop when |r| <= rtol*|b| */
+int pf_pcg_begin(const pf_problem* p, const double* b, double* x, double* ws, double rtol, void* stream);
+/* n_iter CG iterations (no-ops after the stop test fired).  state_out: host double[4] or NULL =
+ * [iterations done, stopped (0/1), |r|^2, |b|^2], read back after a stream synchronisation. */
+int pf_pcg_iterations(const pf_problem* p, double* x, double* ws, int n_iter, double* state_out, void* stream);
+
 /* ---- extensions (off the default path) ------------------------------------------------ */
 /* generic Adam (torch.optim.Adam single-tensor arithmetic) on a flat vector */
 int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step,

@@ -507,6 +507,80 @@ def solve_gd(pb: Problem, config: Optional[SolverConfig] = None,
     return res
 
 
+def assemble_system_f64(pb: Problem, u: np.ndarray):
+    """fem/assembly.py:16-75 with fem/element.py:15-42 (1-D) and :45-102 (2-D linear truss): dense float64
+    K, f_int = sum of ke @ u_e, max |strain|.  Scalar materials only (the NumPy twin has no nets)."""
+    if pb.has_nn():
+        raise ValueError("the float64 NumPy assembly works on scalar materials")
+    ndof = pb.ndof
+    k = np.zeros((ndof, ndof), dtype=float)
+    f = np.zeros(ndof, dtype=float)
+    max_eps = 0.0
+    young, area = float(pb.young), float(pb.area)
+    for ni, nj in pb.elements:
+        if pb.dimension == 1:
+            x = pb.nodes.reshape(-1)
+            l0 = abs(float(x[nj] - x[ni]))                                   # element.py:24-26
+            stiff = (young * area) / l0
+            ke = stiff * np.array([[1.0, -1.0], [-1.0, 1.0]])
+            dofs = np.array([ni, nj])
+            fe = stiff * np.array([u[ni] - u[nj], u[nj] - u[ni]])            # element.py:40
+            eps = (u[nj] - u[ni]) / l0
+        else:
+            dx0 = pb.nodes[nj] - pb.nodes[ni]
+            l0 = float(np.linalg.norm(dx0))                                  # element.py:60-61
+            cx, cy = dx0[0] / l0, dx0[1] / l0
+            dofs = np.array([2 * ni, 2 * ni + 1, 2 * nj, 2 * nj + 1])
+            ue = u[dofs]
+            eps = (cx * (ue[2] - ue[0]) + cy * (ue[3] - ue[1])) / l0        # :70-74
+            stiff = (young * area) / l0
+            c2, s2, cs = cx * cx, cy * cy, cx * cy
+            ke = stiff * np.array([[c2, cs, -c2, -cs], [cs, s2, -cs, -s2],
+                                   [-c2, -cs, c2, cs], [-cs, -s2, cs, s2]])  # :85-95
+            fe = ke @ ue                                                     # :99-100
+        k[np.ix_(dofs, dofs)] += ke
+        f[dofs] += fe
+        max_eps = max(max_eps, abs(float(eps)))
+    return k, f, max_eps
+
+
+def solve_nr(pb: Problem, config: Optional[SolverConfig] = None, target_load_factor: float = 1.0,
+             u_initial=None) -> SolverResult:
+    """fem/solver.py:408-512: Newton-Raphson with a dense float64 solve on K_ff; u starts from zero
+    whatever u_initial says (:443)."""
+    config = config or SolverConfig()
+    if pb.has_nn():
+        raise ValueError("Newton-Raphson solver with NN materials not fully supported yet. "
+                         "Use solve_gd() for problems with NN parameters.")
+    u = np.zeros(pb.ndof, dtype=float)
+    free, fixed = free_and_fixed_dofs(pb.ndof, pb.fixed_dofs)
+    lam = target_load_factor
+    f_ext = lam * pb.loads
+    converged, res_norm, max_e, ite = False, np.inf, 0.0, -1
+    for ite in range(config.max_iterations):
+        k, f_int, max_e = assemble_system_f64(pb, u)
+        rhs = f_ext - f_int
+        try:
+            du_f = np.linalg.solve(k[np.ix_(free, free)], rhs[free])
+        except np.linalg.LinAlgError as exc:
+            raise RuntimeError("Tangent stiffness became singular during solve") from exc
+        du = np.zeros_like(u)
+        du[free] = du_f
+        u += du
+        res_norm = np.linalg.norm(du) / max(np.linalg.norm(u), getattr(config, "min_denominator", 1e-10))
+        if res_norm <= config.tolerance:
+            converged = True
+            break
+    hist = [{"load_factor": float(lam), "iterations": float(ite + 1), "residual": float(res_norm),
+             "max_strain": float(max_e), "converged": float(1.0 if converged else 0.0)}]
+    k, _, _ = assemble_system_f64(pb, u)
+    reactions = k @ u - lam * pb.loads
+    reactions[free] = 0.0
+    shape = (-1, 1) if pb.dimension == 1 else (pb.nnode, pb.dimension)
+    return SolverResult(displacements=u.reshape(shape), reactions=reactions.reshape(shape),
+                        converged=converged, history=hist)
+
+
 def solve_hybrid(pb: Problem, config: Optional[SolverConfig] = None,
                  target_load_factor: float = 1.0, u_initial: Optional[np.ndarray] = None,
                  geo: Optional[Geometry] = None, call_log: Optional[list] = None,
@@ -523,8 +597,16 @@ def solve_hybrid(pb: Problem, config: Optional[SolverConfig] = None,
         gd_res = solve_gd(pb, gd_cfg, target_load_factor, u_initial, True, geo, call_log, fe_mode)
         if gd_res.converged and gd_res.history[-1].get("residual_norm", 1.0) < config.tolerance:
             return gd_res
-    if not pb.has_nn():
-        raise NotImplementedError("scalar-material hybrid uses solve_nr (out of scope, SURVEY §8)")
+    if not pb.has_nn():                                                # :653-692: the GD -> NR switch
+        nr = solve_nr(pb, config, target_load_factor)
+        if gd_res:
+            off = gd_res.history[-1].get("iteration", 0) if gd_res.history else 0
+            merged = list(gd_res.history)
+            last = dict(nr.history[-1])
+            last["iteration"] = off + nr.history[-1].get("iterations", 1)
+            merged.append(last)
+            nr.history = merged
+        return nr
     fin = copy.deepcopy(config)                                        # :600-604
     fin.max_iterations = config.max_iterations - (gd_cfg.max_iterations if gd_res else 0)
     u_warm = gd_res.displacements.flatten().astype(f32) if gd_res else u_initial
@@ -545,7 +627,11 @@ def solve(pb: Problem, config: Optional[SolverConfig] = None,
     """fem/solver.py:1045-1167 (methods gd / hybrid; 'auto' resolves to gd here because the
     NR branch is out of scope)."""
     config = config or SolverConfig()
-    method = config.method.lower() if config.method != "auto" else "gd"
+    if config.method != "auto":
+        method = config.method.lower()
+    else:                                                               # :1075-1090
+        has_meas = pb.measured_vals is not None and pb.measured_dofs is not None
+        method = "gd" if (pb.has_nn() or has_meas) else "nr"
     geo = element_geometry(pb)
     result = None
     u_cur = None
@@ -557,6 +643,8 @@ def solve(pb: Problem, config: Optional[SolverConfig] = None,
             result = solve_gd(pb, config, lam, u0, False, geo, call_log, fe_mode)
         elif method == "hybrid":
             result = solve_hybrid(pb, config, lam, u0, geo, call_log, fe_mode)
+        elif method == "nr":
+            result = solve_nr(pb, config, lam, u0)
         else:
             raise ValueError(f"Unknown solver method: {method}")
         u_cur = result.displacements.flatten()

@@ -123,6 +123,10 @@ SYMBOLS = {
     "pf_shard_backward": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_shard_update_interior": (C.c_int, [_PP, C.c_void_p]),
     "pf_shard_update_shared": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_kv_f64": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "pf_pcg_workspace_count": (C.c_longlong, [_PP]),
+    "pf_pcg_begin": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "pf_pcg_iterations": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
     "pf_comm_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
     "pf_comm_create": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pf_comm_destroy": (C.c_int, [C.c_void_p]),

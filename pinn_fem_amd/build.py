@@ -25,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.j
 
 
 def _sources():
-    units = [("pf_api.o", "pf_api.hip", []), ("pf_mesh.o", "pf_mesh.hip", []), ("pf_comm.o", "pf_comm.hip", [])]
+    units = [("pf_api.o", "pf_api.hip", []), ("pf_mesh.o", "pf_mesh.hip", []), ("pf_comm.o", "pf_comm.hip", []), ("pf_pcg.o", "pf_pcg.hip", [])]
     # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
     # removes the v_accvgpr_read copies in front of every tanh
     units += [(f"pf_net44_{w}.o", "pf_net44.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])

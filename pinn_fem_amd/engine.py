@@ -367,6 +367,42 @@ class HipEngine:
             _capi.check(lib.pf_theta_reduce(ref, 0, s), "pf_theta_reduce")
         return self.grad_u, self.grad_theta[: max(self.n_theta_active, 0)]
 
+    # ---- classical Newton-Raphson support: float64 matrix-free K v and Jacobi-PCG (pf_pcg.hip) ---------
+    @_on_engine_stream
+    def kv_f64(self, v: torch.Tensor, zero_fixed: bool = False) -> torch.Tensor:
+        """K(E, A) v in float64 (fem/assembly.py:16-75 without forming K).  NN properties, if any, must
+        have been evaluated (eval_properties)."""
+        vv = v.to(device=self.device, dtype=torch.float64).contiguous()
+        out = torch.empty(self.plan.n_dofs, dtype=torch.float64, device=self.device)
+        _capi.check(self.lib.pf_kv_f64(self._ref(), vv.data_ptr(), out.data_ptr(), int(zero_fixed), self._stream()),
+                    "pf_kv_f64")
+        return out
+
+    @_on_engine_stream
+    def pcg_solve(self, b: torch.Tensor, rtol: float = 1e-13, max_iter: Optional[int] = None, poll: int = 64):
+        """K_ff x = b by conjugate gradients with the diag(K_ff) preconditioner, float64, on the device.
+        Returns (x with zeros on fixed dofs, iterations, converged)."""
+        n = self.plan.n_dofs
+        bb = b.to(device=self.device, dtype=torch.float64).contiguous()
+        x = torch.zeros(n, dtype=torch.float64, device=self.device)
+        ws = torch.zeros(int(self.lib.pf_pcg_workspace_count(self._ref())), dtype=torch.float64, device=self.device)
+        s = self._stream()
+        _capi.check(self.lib.pf_pcg_begin(self._ref(), bb.data_ptr(), x.data_ptr(), ws.data_ptr(), float(rtol), s),
+                    "pf_pcg_begin")
+        if max_iter is None:
+            max_iter = 3 * n + 50
+        st = (C.c_double * 4)()
+        done_it = 0
+        while True:
+            k = min(poll, max_iter - done_it)
+            _capi.check(self.lib.pf_pcg_iterations(self._ref(), x.data_ptr(), ws.data_ptr(), int(max(k, 0)), st, s),
+                        "pf_pcg_iterations")
+            done_it += max(k, 0)
+            if st[1] != 0.0 or done_it >= max_iter:
+                break
+        converged = st[2] <= (rtol * rtol) * st[3] * 4.0 or st[3] == 0.0     # |r| <= 2 rtol |b|
+        return x, int(st[0]), bool(converged), float(st[2]), float(st[3])
+
     @_on_engine_stream
     def diag_k(self, lam: Optional[float] = None) -> torch.Tensor:
         self.eval_properties(lam)

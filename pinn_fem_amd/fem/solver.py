@@ -9,7 +9,10 @@ steps, each iteration is a fixed sequence of HIP kernels (pf_gd_iterations) work
 resident state; the stop test runs on the device, so the host only polls a 64-byte state record
 every `check_every` iterations and the final state equals the reference's `break`.
 
-Out of scope here: solve_nr (:408-512) and solve_full_nr (:753-1037); calling them
+solve_nr (:408-512, classical Newton-Raphson for scalar materials) runs on the
+device too: matrix-free float64 K v and a Jacobi-preconditioned CG solve replace the dense
+np.linalg.solve, which also gives the scalar branch of solve_hybrid its real GD -> NR switch (:653-692).
+Out of scope: solve_full_nr (:753-1037, non-functional in the reference); calling it
 raises NotImplementedError.
 """
 from __future__ import annotations
@@ -286,10 +289,69 @@ def _solve_gd_sharded(model, config, measured_disp, measured_dofs, lam, u_initia
 
 
 def solve_nr(model, config=None, target_load_factor=1.0, u_initial=None) -> SolverResult:
-    """Classical Newton-Raphson (solver.py:408-512) — out of scope of the HIP path."""
-    raise NotImplementedError(
-        "solve_nr (dense NumPy Newton-Raphson, scalar materials only) is outside the accelerated "
-        "PINN+GD path; use the reference implementation for method='nr'")
+    """Classical Newton-Raphson for scalar materials (solver.py:408-512), SURVEY.md §8(f) rank 3.
+
+    The reference assembles the dense float64 tangent (fem/assembly.py:16-75) and calls
+    np.linalg.solve on K_ff; here K is applied matrix-free in float64 on the device (pf_kv_f64) and
+    K_ff du = rhs is solved by conjugate gradients with the diag(K_ff) (Jacobi) preconditioner
+    (pf_pcg_*), so the solver no longer stops at the ~2*10^4 dofs a dense K allows.  Same loop, same
+    stopping rule (|du| / max(|u|, min_denominator) <= tolerance), same history record; like the
+    reference, u starts from zero whatever u_initial says (:443)."""
+    config = config or SolverConfig()
+    if model.material.has_trainable_params():
+        raise ValueError("Newton-Raphson solver with NN materials not fully supported yet. "
+                         "Use solve_gd() for problems with NN parameters.")
+    eng = _engine_for(model, None, None)
+    ndof = model.ndof
+    free = np.ones(ndof, dtype=bool)
+    free[np.asarray(model.fixed_dofs, dtype=int)] = False
+    load_factor = target_load_factor
+    f_ext = torch.from_numpy(np.ascontiguousarray(load_factor * np.asarray(model.loads, dtype=float))).to(eng.device)
+    u = torch.zeros(ndof, dtype=torch.float64, device=eng.device)
+    # a free dof no element stiffens makes K_ff singular: np.linalg.solve raises there (solver.py:462-467)
+    if bool((eng.diag_k().cpu().numpy()[free] == 0.0).any()):
+        raise RuntimeError("Tangent stiffness became singular during solve")
+    has_converged, residual_norm, max_e, ite = False, float("inf"), 0.0, -1
+    for ite in range(config.max_iterations):
+        max_e = _max_abs_strain(model, u)
+        rhs = f_ext - eng.kv_f64(u)
+        du, _, ok, rr, bb = eng.pcg_solve(rhs)
+        if not ok or not np.isfinite(rr):
+            raise RuntimeError("Tangent stiffness became singular during solve")
+        u = u + du
+        residual_norm = float(torch.linalg.norm(du)) / max(float(torch.linalg.norm(u)), config.min_denominator)
+        if residual_norm <= config.tolerance:
+            has_converged = True
+            break
+    history = [{"load_factor": float(load_factor), "iterations": float(ite + 1), "residual": float(residual_norm),
+                "max_strain": float(max_e), "converged": float(1.0 if has_converged else 0.0)}]
+    reactions = (eng.kv_f64(u) - f_ext).cpu().numpy()
+    reactions[free] = 0.0
+    u_np = u.cpu().numpy()
+    shape = (-1, 1) if model.dimension == 1 else (model.nnode, model.dimension)
+    return SolverResult(displacements=u_np.reshape(shape), reactions=reactions.reshape(shape),
+                        converged=has_converged, history=history)
+
+
+def _max_abs_strain(model, u) -> float:
+    """max |epsilon| over the elements, epsilon = axial stretch / l0 (fem/element.py:27-28, 74-80): a
+    monitor of the history record only (host, float64)."""
+    uu = u.detach().cpu().numpy().astype(float)
+    nodes = np.asarray(model.nodes, dtype=float)
+    el = np.asarray(model.elements, dtype=int)
+    if el.size == 0:
+        return 0.0
+    if model.dimension == 1:
+        x = nodes.reshape(-1)
+        l0 = np.abs(x[el[:, 1]] - x[el[:, 0]])
+        eps = (uu[el[:, 1]] - uu[el[:, 0]]) / l0
+    else:
+        d0 = nodes[el[:, 1]] - nodes[el[:, 0]]
+        l0 = np.linalg.norm(d0, axis=1)
+        U = uu.reshape(-1, 2)
+        du = U[el[:, 1]] - U[el[:, 0]]
+        eps = ((d0[:, 0] / l0) * du[:, 0] + (d0[:, 1] / l0) * du[:, 1]) / l0
+    return float(np.max(np.abs(eps)))
 
 
 def solve_full_nr(*args, **kwargs) -> SolverResult:
@@ -335,8 +397,26 @@ def solve_hybrid(
     _say("Phase 2: Newton-Raphson Finalization...")
     has_nn = model.material.has_trainable_params()
     if not has_nn:
-        # scalar materials switch to the dense NumPy Newton-Raphson (solver.py:653-692): out of scope
-        return solve_nr(model, config, target_load_factor, u_initial)
+        # scalar materials: the real GD -> NR switch (solver.py:653-692)
+        _say("  Scalar materials detected. Using Newton-Raphson.")
+        u_warm = (torch.tensor(gd_result.displacements.flatten(), dtype=torch.float32)
+                  if gd_result else u_initial)
+        nr_result = solve_nr(model, config, target_load_factor, u_warm)
+        nr_iterations = nr_result.history[-1].get("iterations", 1) if nr_result.history else 1
+        _say(f"  NR Phase: {nr_iterations} iterations")
+        if gd_result:
+            gd_iterations = gd_result.history[-1].get("iteration", 0) if gd_result.history else 0
+            total_iterations = gd_iterations + nr_iterations
+            unified_history = []
+            if gd_result.history:
+                unified_history.extend(gd_result.history)
+            if nr_result.history:
+                nr_entry = nr_result.history[-1].copy()
+                nr_entry["iteration"] = total_iterations
+                unified_history.append(nr_entry)
+            nr_result.history = unified_history
+        _say(f"  Hybrid Total: {nr_result.history[-1].get('iteration', nr_iterations)} iterations")
+        return nr_result
     _say("  NN parameters detected. Using GD for final convergence with tight tolerance.")
     final_config = copy.deepcopy(config)
     final_config.max_iterations = config.max_iterations - (gd_config.max_iterations if gd_result else 0)

@@ -48,7 +48,9 @@ ref_generic = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(ref_generic)
 
 EXAMPLES = ["example2", "example2-P", "example3", "example3-P", "example4", "example4-P",
-            "example6", "example6-P", "example7", "example7-P"]
+            "example6", "example6-P", "example7", "example7-P",
+            # classical Newton-Raphson (solver_type fem) and hybrid with scalar materials (GD -> NR switch)
+            "example1", "example1-1", "example5", "example5-P"]
 
 
 def quiet():
@@ -352,6 +354,32 @@ def gen_meshes():
     save_npz("step_example2_scalar.npz", **rec)
 
 
+# ----------------------------------------------------------------------------------
+# (6) classical Newton-Raphson on the fixture meshes with scalar materials (fem/solver.py:408-512)
+# ----------------------------------------------------------------------------------
+def gen_nr_meshes():
+    from fem.model import FEMModel, Material
+    from fem.solver import SolverConfig, solve_nr
+    for src, name, young, area, lam in (("step_warren_EA.npz", "nr_warren_scalar.npz", 2.0, 0.5, 0.7),
+                                        ("step_chain300_ex4shape.npz", "nr_chain300_scalar.npz", 1.0, 1.0, 1.0)):
+        with np.load(os.path.join(HERE, src)) as z:
+            rec = {k: z[k] for k in z.files}
+        nodes = np.asarray(rec["nodes"], dtype=float)
+        elements = [tuple(int(v) for v in e) for e in rec["elements"]]
+        loads = np.asarray(rec["loads"], dtype=float)
+        fixed = [int(v) for v in rec["fixed"]]
+        model = FEMModel(nodes=nodes, elements=elements, material=Material(young, area, 1.0), loads=loads,
+                         fixed_dofs=fixed, dimension=2)
+        cfg = SolverConfig(max_iterations=20, tolerance=1e-10)
+        with quiet():
+            res = solve_nr(model, cfg, target_load_factor=lam)
+        save_npz(name, nodes=nodes, elements=np.asarray(elements), loads=loads, fixed=np.asarray(fixed),
+                 young=young, area=area, lam=lam, tolerance=cfg.tolerance,
+                 u=res.displacements.reshape(-1), reactions=res.reactions.reshape(-1),
+                 iterations=res.history[-1]["iterations"], converged=res.converged)
+        print(f"  wrote {name}: {len(elements)} elements, NR iterations {res.history[-1]['iterations']}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None,
@@ -374,6 +402,9 @@ def main():
     if "meshes" in todo:
         print("[meshes]")
         gen_meshes()
+    if "meshes" in todo or "nr" in todo:
+        print("[nr meshes]")
+        gen_nr_meshes()
     run_names = [e for e in EXAMPLES if "runs" in todo or e in todo]
     if run_names:
         print("[runs]")

@@ -553,10 +553,10 @@ def test_error_behaviour_matches_reference_semantics():
     with pytest.raises(RuntimeError, match="cannot be multiplied"):
         solve_gd(bad, SolverConfig(max_iterations=2))
     ok = FEMModel(nodes[:2], np.array([[0, 1]]), Material(1.0, 1.0), np.array([0, 0, 1.0, 0]), np.array([0, 1, 3]))
-    with pytest.raises(NotImplementedError):                           # scalar hybrid -> solve_nr (out of scope)
-        solve_hybrid(ok, SolverConfig(max_iterations=20))
-    with pytest.raises(NotImplementedError):                           # auto + no NN + no data -> nr
-        solve(ok, SolverConfig(max_iterations=20))
+    rh = solve_hybrid(ok, SolverConfig(max_iterations=20))            # scalar hybrid -> solve_nr (solver.py:653-692)
+    assert rh.converged and abs(rh.displacements[1, 0] - 1.0) < 1e-12 and rh.history[-1]["iterations"] == 2.0
+    ra = solve(ok, SolverConfig(max_iterations=20))                    # auto + no NN + no data -> nr (:1077-1079)
+    assert ra.converged and abs(ra.displacements[1, 0] - 1.0) < 1e-12
     with pytest.raises(ValueError, match="Unknown solver method"):
         solve(ok, SolverConfig(method="bogus"))
     r = solve(ok, SolverConfig(method="gd", max_iterations=400, learning_rate_u=0.01, n_increments=2))
@@ -608,3 +608,61 @@ def test_sharded_c_driver_real_rccl_world1():
     got = json.loads(line)
     assert got["iters"] == [40, 40]
     assert got["rel_err_u"] == 0.0 and got["rel_err_theta"] == 0.0, got
+
+
+# ---- classical Newton-Raphson on the device ------------------------------------
+@pytest.mark.parametrize("name", ["nr_warren_scalar.npz", "nr_chain300_scalar.npz"])
+def test_newton_raphson_meshes_vs_reference(name):
+    """solve_nr (matrix-free float64 K v + Jacobi-PCG on the device) against the reference's dense float64
+    Newton-Raphson on the fixture meshes.  Tolerance 1e-6 relative: the device geometry (c^2, cs, s^2, l0) is
+    the float32 rounding of the reference's float64 values (the plan the GD kernels share)."""
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.solver import SolverConfig, solve_nr
+    rec = load_npz(name)
+    model = FEMModel(nodes=rec["nodes"], elements=rec["elements"],
+                     material=Material(float(rec["young"]), float(rec["area"]), 1.0), loads=rec["loads"],
+                     fixed_dofs=rec["fixed"], dimension=2)
+    res = solve_nr(model, SolverConfig(max_iterations=20, tolerance=float(rec["tolerance"])),
+                   target_load_factor=float(rec["lam"]))
+    assert res.converged == bool(rec["converged"])
+    assert res.history[-1]["iterations"] == float(rec["iterations"])
+    assert rel_err(res.displacements.reshape(-1), rec["u"]) < 1e-6
+    assert np.max(np.abs(res.reactions.reshape(-1) - rec["reactions"])) < 1e-6 * max(1.0, np.max(np.abs(rec["reactions"])))
+
+
+@pytest.mark.parametrize("ex", ["example1", "example1-1", "example5", "example5-P"])
+def test_nr_and_scalar_hybrid_example_runs(ex):
+    """`generic.py example1|1-1|5|5-P.json`: classical FEM (NR) and the scalar hybrid's GD -> NR switch,
+    against the reference's results (integer-coordinate chains: exact geometry, so 1e-9)."""
+    from pinn_fem_amd.cli import generic as g
+    run = load_run(ex)
+    out = g.solve_problem(product_example(ex))
+    ref = run["result"]
+    assert out["converged"] == ref["converged"]
+    assert rel_err(out["displacements"], ref["displacements"]) < 1e-9
+    assert np.max(np.abs(np.array(out["reactions"]) - np.array(ref["reactions"]))) < 1e-9
+    last, rlast = out["history"][-1], ref["history"][-1]
+    assert last["iterations"] == rlast["iterations"] and last["converged"] == rlast["converged"]
+    assert abs(last["max_strain"] - rlast["max_strain"]) < 1e-9
+    if "iteration" in rlast:
+        assert abs(last["iteration"] - rlast["iteration"]) <= 3
+    assert abs(out["iterations"] - ref["iterations"]) <= 3
+
+
+def test_newton_raphson_errors_like_the_reference():
+    """NN materials are refused with the reference's ValueError (solver.py:436-441); a mechanism (a free
+    dof no element holds) raises the reference's RuntimeError instead of returning garbage."""
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.properties import NNProperty
+    from pinn_fem_amd.fem.solver import SolverConfig, solve_nr
+    from pinn_fem_amd.nets import SimpleNN
+    nodes = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0]])
+    el = np.array([[0, 1], [1, 2]])
+    loads = np.array([0, 0, 0, 0, 1.0, 0.0])
+    nn_model = FEMModel(nodes, el, Material(NNProperty(SimpleNN(2, 8, 3), input_dim=3, scale=1.0), 1.0, 1.0),
+                        loads, np.array([0, 1, 3, 5]))
+    with pytest.raises(ValueError, match="Newton-Raphson solver with NN materials"):
+        solve_nr(nn_model, SolverConfig())
+    mech = FEMModel(nodes, el, Material(1.0, 1.0, 1.0), np.array([0, 0, 0, 1.0, 0, 0]), np.array([0, 1]))
+    with pytest.raises(RuntimeError, match="singular"):
+        solve_nr(mech, SolverConfig(max_iterations=3))

@@ -177,3 +177,37 @@ def test_known_answer_45deg_bar():
     assert abs(f[2] - 5.0) < 1e-5 and abs(f[3] - 5.0) < 1e-5
     axial = np.hypot(f[2], f[3])
     assert abs(axial - 7.0711) < 1e-3
+
+
+# ---- classical Newton-Raphson (fem/solver.py:408-512) and the scalar GD -> NR hybrid (:653-692) -------
+@pytest.mark.parametrize("name", ["nr_warren_scalar.npz", "nr_chain300_scalar.npz"])
+def test_oracle_newton_raphson_meshes(name):
+    """The oracle's dense float64 restatement of solve_nr reproduces the reference on the fixture meshes
+    (19-element Warren truss, 300-element chain) to float64 round-off."""
+    rec = load_npz(name)
+    pb = orc.Problem(nodes=rec["nodes"], elements=rec["elements"], loads=rec["loads"], fixed_dofs=rec["fixed"],
+                     dimension=2, young=float(rec["young"]), area=float(rec["area"]), density=1.0)
+    res = orc.solve_nr(pb, orc.SolverConfig(max_iterations=20, tolerance=float(rec["tolerance"])), float(rec["lam"]))
+    assert res.converged == bool(rec["converged"])
+    assert res.history[-1]["iterations"] == float(rec["iterations"])
+    assert rel_err(res.displacements.reshape(-1), rec["u"]) < 1e-12
+    assert np.max(np.abs(res.reactions.reshape(-1) - rec["reactions"])) < 1e-10
+
+
+@pytest.mark.parametrize("ex", ["example1", "example1-1", "example5", "example5-P"])
+def test_oracle_nr_and_scalar_hybrid_runs(ex):
+    """Whole runs of the classical-FEM examples (solver_type fem -> NR) and the scalar hybrid examples
+    (GD phase then the NR switch): displacements, reactions, converged, NR history record."""
+    run = load_run(ex)
+    pb, cfg = example_problem(ex)
+    res = orc.solve(pb, cfg)
+    ref = run["result"]
+    assert res.converged == ref["converged"]
+    assert rel_err(res.displacements.reshape(-1), ref["displacements"]) < 1e-12
+    assert np.max(np.abs(res.reactions.reshape(-1) - np.array(ref["reactions"]))) < 1e-12
+    last, rlast = res.history[-1], ref["history"][-1]
+    assert last["iterations"] == rlast["iterations"] and last["converged"] == rlast["converged"]
+    assert abs(last["max_strain"] - rlast["max_strain"]) < 1e-12
+    if "iteration" in rlast:          # hybrid with a GD phase: unified iteration count (solver.py:676-684)
+        assert abs(last["iteration"] - rlast["iteration"]) <= 3
+        assert abs(len(res.history) - len(ref["history"])) <= 3
