@@ -135,3 +135,43 @@ def chain_mesh(n_elems: int, h: float = 1.0):
     meas_dofs = np.stack([2 * k, 2 * k + 1], axis=1).reshape(-1)
     meas_vals = np.stack([x[1:], np.zeros(n)], axis=1).reshape(-1)
     return nodes, elements, loads, fixed, meas_vals, meas_dofs
+
+
+def warren_mesh(n_panels: int, h: float = 1.0, height: float = 1.0):
+    """Synthetic Warren girder (a genuinely 2-D truss, node degree 4): bottom chord nodes (i*h, 0),
+    i = 0..n, top chord nodes ((i+0.5)*h, height), i = 0..n-1; elements per panel, in mesh order: bottom
+    chord, rising diagonal, falling diagonal, top chord -> 4n-1 elements.  Pin at the first bottom node,
+    roller (uy) at the last, unit downward load on every interior bottom node, measurements at every free
+    node dof (a smooth synthetic sag plus a horizontal drift, non-zero at every dof so that Adam never
+    normalises pure round-off; throughput runs only need the shape)."""
+    n = int(n_panels)
+    xb = np.arange(n + 1, dtype=np.float64) * h
+    xt = (np.arange(n, dtype=np.float64) + 0.5) * h
+    # interleave bottom and top nodes so that neighbouring nodes stay close in memory: b0 t0 b1 t1 ... bn
+    nodes = np.zeros((2 * n + 1, 2))
+    nodes[0::2, 0] = xb
+    nodes[1::2, 0] = xt
+    nodes[1::2, 1] = height
+    b = lambda i: 2 * i          # node id of bottom node i
+    t = lambda i: 2 * i + 1      # node id of top node i
+    i = np.arange(n)
+    per_panel = [np.stack([b(i), b(i + 1)], 1), np.stack([b(i), t(i)], 1), np.stack([t(i), b(i + 1)], 1)]
+    top = np.stack([t(i[:-1]), t(i[:-1] + 1)], 1)
+    el = np.empty((4 * n - 1, 2), dtype=np.int64)
+    el[0:4 * (n - 1):4] = per_panel[0][:-1]
+    el[1:4 * (n - 1):4] = per_panel[1][:-1]
+    el[2:4 * (n - 1):4] = per_panel[2][:-1]
+    el[3:4 * (n - 1):4] = top
+    el[4 * (n - 1):] = np.stack([per_panel[0][-1], per_panel[1][-1], per_panel[2][-1]])
+    loads = np.zeros(2 * (2 * n + 1))
+    loads[2 * b(np.arange(1, n)) + 1] = -1.0
+    fixed = np.array([0, 1, 2 * b(n) + 1])
+    free = np.ones(2 * (2 * n + 1), dtype=bool)
+    free[fixed] = False
+    meas_dofs = np.flatnonzero(free)
+    span = max(xb[-1], 1.0)
+    sag = -1e-3 * np.sin(np.pi * nodes[:, 0] / span)
+    vals = np.zeros(2 * (2 * n + 1))
+    vals[0::2] = 2e-4 * (0.1 + nodes[:, 0] / span)     # non-zero everywhere: no dof with a round-off-sized gradient
+    vals[1::2] = sag - 1e-4
+    return nodes, el, loads, fixed, vals[meas_dofs], meas_dofs
