@@ -264,6 +264,8 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        from pinn_fem_amd.dist import destroy_rccl_comms
+        destroy_rccl_comms()
         dist.destroy_process_group()
 
 

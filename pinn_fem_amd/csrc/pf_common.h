@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "pinnfem_hip.h"
 
 #define PF_WAVE 64
@@ -189,10 +190,32 @@ __device__ __forceinline__ float pf_elem_gea(const pf_problem& P, int e) {
   return gs / g.l0;  // div backward of (young*area)/l0
 }
 
-// blocks the element-parallel net kernels launch for n elements
-__host__ __device__ inline int pf_net_blocks(int n_elems, int n_part_blocks) {
-  int nb = (n_elems + PF_NET_THREADS - 1) / PF_NET_THREADS;
-  if (nb > n_part_blocks) nb = n_part_blocks;
+// blocks the element-parallel net kernels launch for n elements = rows of per-block partial weight
+// gradients the theta reduction sums.  The MFMA44 engine runs up to 8 waves per block (one block per CU at
+// two waves per SIMD: the same residency as 2-wave blocks, a quarter of the partial rows); the wave count is
+// the largest of 8/4/2 whose gradient-tile LDS image (pf_net44.hip: Row<L>) fits 160 KiB for EVERY enabled
+// net, so both backward kernels of a problem write the same number of rows.
+#define PF_NET44_MAX_THREADS 512
+#define PF_NET44_CS 36   /* floats per LDS column (Row<L>::CS) */
+__host__ __device__ constexpr int pf_net44_row_len(int hp, int nh) { return nh * hp + 8 + nh * (hp + 4); }
+inline int pf_net44_threads(const pf_problem* p) {
+  // PF_NET44_THREADS (128 | 256 | 512): experiment knob
+  static const int knob = getenv("PF_NET44_THREADS") ? atoi(getenv("PF_NET44_THREADS")) : PF_NET44_MAX_THREADS;
+  int waves = (knob >= 128 && knob <= PF_NET44_MAX_THREADS ? knob : PF_NET44_MAX_THREADS) / 64;
+  for (int k = 0; k < 2; ++k) {
+    if (!p->net[k].enabled) continue;
+    const int hp = ((p->net[k].width + 3) / 4) * 4;
+    while (waves > 2 && (size_t)waves * pf_net44_row_len(hp, p->net[k].n_hidden) * PF_NET44_CS * 4 > 160u * 1024u) waves >>= 1;
+  }
+  return waves * 64;
+}
+inline int pf_net_blocks(const pf_problem* p) {
+  const bool m44 = p->wg_mode == PF_WG_MFMA44;
+  const int threads = m44 ? pf_net44_threads(p) : PF_NET_THREADS;
+  int cap = m44 ? p->n_part_blocks * PF_NET_THREADS / threads : p->n_part_blocks;   // same number of waves
+  if (cap < 1) cap = 1;
+  int nb = (p->mesh.n_elems + threads - 1) / threads;
+  if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   return nb;
 }

@@ -728,7 +728,7 @@ int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int 
 
 int pf_launch_theta_stage1(const pf_problem* p, hipStream_t s) {
   if (p->n_theta_active <= 0) return PF_OK;
-  const int nb_rows = pf_net_blocks(p->mesh.n_elems, p->n_part_blocks);
+  const int nb_rows = pf_net_blocks(p);
   hipLaunchKernelGGL(k_theta_stage1, dim3((p->pad_total + 63) / 64, PF_RG), dim3(256), 0, s, *p, nb_rows);
   return PF_CHECK_LAUNCH();
 }

@@ -354,7 +354,7 @@ int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
 
 template <int L, int IN>
 int launch_bwd(const pf_problem* p, int which, hipStream_t s) {
-  const int nb = pf_net_blocks(p->mesh.n_elems, p->n_part_blocks);
+  const int nb = pf_net_blocks(p);
   constexpr int PADC = pf_pad_count(HP, L);
   if (p->wg_mode == PF_WG_MFMA) {
     constexpr int tile_floats = WAVES * TILES_PER_WAVE * TILE;

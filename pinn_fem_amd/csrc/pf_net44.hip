@@ -317,7 +317,7 @@ struct Row {
   // LDS image of one pass (32 elements) is COLUMN-major: column c of element q at c*CS + q, so the 4x4
   // tile operands of 4 consecutive elements come back from ONE ds_read_b128 with an immediate offset
   // (no address arithmetic between the MFMAs).  CS = 36 = 4 (mod 32) spreads the columns over banks.
-  static constexpr int CS = 36;
+  static constexpr int CS = PF_NET44_CS;
   static constexpr int NT_L1 = NB;
   static constexpr int NT_H = (L - 1) * NB * (NB + 1);
   static constexpr int NT_O = NB + 1;
@@ -344,8 +344,7 @@ struct Row {
 };
 
 // ---- backward kernel -------------------------------------------------------------------------------------
-constexpr int BW_THREADS = PF_NET_THREADS;
-constexpr int BW_WAVES = BW_THREADS / 64;
+constexpr int BW_MAX_THREADS = PF_NET44_MAX_THREADS;   // blocks run pf_net44_threads(p) <= this (runtime blockDim.x)
 
 // Inputs of one task (64 elements per wave), fetched ONE TASK AHEAD so that no global-memory latency
 // sits between two tasks of a wave (two waves per SIMD cannot hide it: measured 28 % of the wave
@@ -409,7 +408,7 @@ __device__ __forceinline__ float task_gea(const TaskIn<DIM>& t, int fe_mode) {
 // the register budget is the full 256: no scratch spills, room for the prefetched task and for
 // double-buffered gradient-tile operands.
 template <int L, int IN, bool GEA>
-__global__ __launch_bounds__(BW_THREADS, 2) void k_net44_backward(pf_problem P, int which) {
+__global__ __launch_bounds__(BW_MAX_THREADS, 2) void k_net44_backward(pf_problem P, int which) {
   extern __shared__ __align__(16) float lds[];
   using W = WIdx<L>;
   using R = Row<L>;
@@ -429,8 +428,9 @@ __global__ __launch_bounds__(BW_THREADS, 2) void k_net44_backward(pf_problem P, 
   float wo[HP + 1];
   load_out_weights(wo, w, L);
   // first task's operands go out together with the weights, ahead of the stop-flag test
-  const int stride = gridDim.x * BW_THREADS;
-  int base = blockIdx.x * BW_THREADS;
+  const int bw_threads = blockDim.x, bw_waves = blockDim.x >> 6;
+  const int stride = gridDim.x * bw_threads;
+  int base = blockIdx.x * bw_threads;
   TaskIn<DIM> nxt;
   task_fetch_a<IN, GEA>(nxt, P, onet, other, base + (int)threadIdx.x, base + (int)threadIdx.x < n);
   if (P.state->done) return;
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(BW_THREADS, 2) void k_net44_backward(pf_problem P, 
 
   // ---- write-out: tiles -> per-wave padded image in LDS -> fixed-order sum over waves -> partial row -----------
   __syncthreads();
-  for (int i = threadIdx.x; i < BW_WAVES * PADC; i += BW_THREADS) lds[i] = 0.f;
+  for (int i = threadIdx.x; i < bw_waves * PADC; i += bw_threads) lds[i] = 0.f;
   __syncthreads();
   float* wimg = lds + wvid * PADC;
   sfor<0, M>([&](auto m) {
@@ -616,10 +616,9 @@ __global__ __launch_bounds__(BW_THREADS, 2) void k_net44_backward(pf_problem P, 
   });
   __syncthreads();
   float* __restrict__ prow = P.partials + PF_PART_WG + (size_t)blockIdx.x * P.pad_total + net.pad_off;
-  for (int i = threadIdx.x; i < PADC; i += BW_THREADS) {
+  for (int i = threadIdx.x; i < PADC; i += bw_threads) {
     float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < BW_WAVES; ++q) t += lds[q * PADC + i];
+    for (int q = 0; q < bw_waves; ++q) t += lds[q * PADC + i];
     prow[i] = t;
   }
 }
@@ -648,12 +647,17 @@ int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
 
 template <int L, int IN, bool GEA>
 int launch_bwd_t(const pf_problem* p, int which, hipStream_t s) {
-  const int nb = pf_net_blocks(p->mesh.n_elems, p->n_part_blocks);
+  const int nb = pf_net_blocks(p);
+  const int threads = pf_net44_threads(p), waves = threads / 64;
   constexpr int PADC = pf_pad_count(HP, L);
-  constexpr int row_floats = BW_WAVES * Row<L>::LEN * Row<L>::CS;
-  constexpr int lds_floats = row_floats > BW_WAVES * PADC ? row_floats : BW_WAVES * PADC;
-  static_assert(lds_floats * 4 <= 160 * 1024, "LDS budget");
-  hipLaunchKernelGGL((k_net44_backward<L, IN, GEA>), dim3(nb), dim3(BW_THREADS), lds_floats * sizeof(float), s,
+  static_assert(pf_net44_row_len(HP, L) == Row<L>::LEN, "host LDS sizing out of step with Row<L>");
+  const int row_floats = waves * Row<L>::LEN * Row<L>::CS;
+  const int lds_floats = row_floats > waves * PADC ? row_floats : waves * PADC;
+  if ((size_t)lds_floats * 4 > 160u * 1024u) {
+    pf_set_error("net too large for the gradient-tile LDS image");
+    return PF_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL((k_net44_backward<L, IN, GEA>), dim3(nb), dim3(threads), lds_floats * sizeof(float), s,
                      *p, which);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }

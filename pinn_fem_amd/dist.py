@@ -231,6 +231,16 @@ def rccl_comm(backend, group=None):
     return comm
 
 
+def destroy_rccl_comms():
+    """Release the C driver's communicators (call before torch.distributed.destroy_process_group)."""
+    lib = _capi.load()
+    for comm in list(_RCCL_COMMS.values()):
+        if comm is not None:
+            torch.cuda.synchronize()
+            lib.pf_comm_destroy(comm)
+    _RCCL_COMMS.clear()
+
+
 def run_iterations(backend: ShardBackend, n_iter: int, group=None,
                    bufs: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
     """n_iter GD iterations with the two collectives per iteration of the module docstring (+ one

@@ -62,6 +62,8 @@ def main():
     out["rel_err_theta"] = float(max(np.max(np.abs(r[1] - th_1)) for r in res.values()) / np.max(np.abs(th_1)))
     out["python_driver_iters"] = res["python"][2]
     print(json.dumps(out))
+    from pinn_fem_amd.dist import destroy_rccl_comms
+    destroy_rccl_comms()
     dist.destroy_process_group()
     assert out["rel_err_u"] < 1e-5 and out["rel_err_theta"] < 1e-5, out
 
