@@ -716,3 +716,28 @@ def test_warren_girder_vs_oracle(panels):
         model = product_model(nodes, elements, loads, fixed, 2, widths, (2.0, 0.5, 1.0), theta)
         pb.young = orc.NetParams([t.copy() for t in theta[0:6]], 2.0)
         pb.area = orc.NetParams([t.copy() for t in theta[6:12]], 0.5)
+
+
+def test_newton_raphson_1d_bar_vs_oracle():
+    """dimension = 1 (list-format nodes; fem/element.py:15-42): the float64 K v / Jacobi-PCG kernels' 1-D
+    instantiation against the oracle's dense restatement of solve_nr on a non-uniform 40-element bar."""
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.solver import SolverConfig, solve_nr
+    rng = np.random.default_rng(11)
+    x = np.concatenate([[0.0], np.cumsum(0.5 + rng.random(40))])
+    el = np.stack([np.arange(40), np.arange(1, 41)], axis=1)
+    loads = np.zeros(41)
+    loads[40] = 2.0
+    loads[17] = -0.7
+    fixed = np.array([0])
+    model = FEMModel(nodes=x, elements=el, material=Material(3.0, 0.25, 1.0), loads=loads, fixed_dofs=fixed,
+                     dimension=1)
+    res = solve_nr(model, SolverConfig(max_iterations=10, tolerance=1e-10), target_load_factor=0.8)
+    pb = orc.Problem(nodes=x, elements=el, loads=loads, fixed_dofs=fixed, dimension=1, young=3.0, area=0.25,
+                     density=1.0)
+    ref = orc.solve_nr(pb, orc.SolverConfig(max_iterations=10, tolerance=1e-10), 0.8)
+    assert res.converged and ref.converged and res.history[-1]["iterations"] == ref.history[-1]["iterations"]
+    # float32 element lengths in the device plan: 1e-6
+    assert rel_err(res.displacements.reshape(-1), ref.displacements.reshape(-1)) < 1e-6
+    assert np.max(np.abs(res.reactions.reshape(-1) - ref.reactions.reshape(-1))) < 1e-6
+    assert abs(res.history[-1]["max_strain"] - ref.history[-1]["max_strain"]) < 1e-6 * ref.history[-1]["max_strain"]
