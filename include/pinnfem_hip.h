@@ -147,7 +147,9 @@ typedef struct pf_problem {
    * interface all-reduce overlaps the full forward pass); NULL / 0 on one GPU */
   const int32_t* iface_elems;
   int32_t n_iface_elems;
-  int32_t _pad_iface;
+  /* != 0: prop_e and prop_a hold 2*n_elems floats; the iteration graph then alternates between the two
+   * halves, so the forwards of iteration t+1 need not wait for the last reader of iteration t's properties */
+  int32_t prop_double;
 } pf_problem;
 
 #define PF_MAX_BLOCKS 1024

@@ -80,7 +80,7 @@ class PfProblem(C.Structure):
         ("n_meas_f", C.c_float), ("fe_mode", C.c_int32),
         ("shared_dofs", C.c_void_p), ("shared_slot", C.c_void_p),
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
-        ("iface_elems", C.c_void_p), ("n_iface_elems", C.c_int32), ("_pad_iface", C.c_int32),
+        ("iface_elems", C.c_void_p), ("n_iface_elems", C.c_int32), ("prop_double", C.c_int32),
     ]
 
 

@@ -350,11 +350,36 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   }
   const bool fuse_gea = p->wg_mode == PF_WG_MFMA44;
   const int first = p->net[0].enabled ? 0 : 1;
+  // The runtime keeps the FIRST-created child of a node on its parent's hardware queue and moves later
+  // children to other queues; a dependency whose last parent sits on another queue costs ~10 us (kernel trace).
+  // So the nodes are created in the order that keeps the critical chain (forwards, residual, backwards,
+  // theta) on one queue: finalize(i-1) is created AFTER the forwards of iteration i (PF_GRAPH_ORDER=0: the
+  // older order, finalize first; experiment knob).
+  static const bool late_fin = !(getenv("PF_GRAPH_ORDER") && atoi(getenv("PF_GRAPH_ORDER")) == 0);
+  static const bool pp_knob = !(getenv("PF_GRAPH_PINGPONG") && atoi(getenv("PF_GRAPH_PINGPONG")) == 0);
+  const bool pingpong = p->prop_double != 0 && pp_knob && late_fin;
+  auto capture_finalize = [&](int i) -> int {   // branch B: behind stage 2 (e[2]) and gradu (e[1]) of iteration i
+    hipEvent_t* e = c.ev + PF_CAP_EV * i;
+    if (hipStreamWaitEvent(c.b, e[2], 0) != hipSuccess || hipStreamWaitEvent(c.b, e[1], 0) != hipSuccess)
+      return fail(PF_ERR_HIP, "graph edge failed");
+    PF_TRY(pf_launch_finalize(p, 0, 0, c.b), "finalize");
+    if (hipEventRecord(e[3], c.b) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    return PF_OK;
+  };
   for (int i = 0; i < iters; ++i) {
     hipEvent_t* e = c.ev + PF_CAP_EV * i;
     hipEvent_t* ep = c.ev + PF_CAP_EV * (i - 1);
-    // gradu(i-1) still reads the properties the forwards overwrite, and writes the u the residual reads
-    if (i > 0 && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    // Property buffers ping-pong between iterations (prop_double), so the forwards of iteration i do not wait
+    // for gradu(i-1), the last reader of the other half: the main chain then has ONE incoming edge from another
+    // queue per iteration (finalize(i-1) -> residual(i), which also covers gradu(i-1) -> u) and it has ~25 us of
+    // slack.  Without the second half the forwards wait for gradu(i-1) (an 11 us hole in the kernel trace).
+    pf_problem q = *p;
+    const pf_problem* p = &q;   // (shadows the argument for the rest of this iteration)
+    if (pingpong && (i & 1)) {
+      q.prop_e += q.mesh.n_elems;
+      q.prop_a += q.mesh.n_elems;
+    }
+    if (i > 0 && !pingpong && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
     // the two forwards are independent, but running the second on branch A beside the first measured
     // SLOWER (0.195 vs 0.190 ms per iteration): both are bound by the same f32 pipe.  PF_FWD_PARALLEL=1 keeps
     // the experiment reachable.
@@ -369,25 +394,37 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
       for (int k = 0; k < 2; ++k)
         if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
     }
+    if (i > 0 && late_fin) {
+      int rc = capture_finalize(i - 1);
+      if (rc != PF_OK) return rc;
+    }
     // finalize(i-1) reads the block partials node_residual rewrites, and writes the Adam scalars
     if (i > 0 && hipStreamWaitEvent(s, ep[3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
     PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
     if (!fuse_gea) {
       PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
-      if (cap_edge(e[0], s, c.a) != PF_OK) return PF_ERR_HIP;
+      if (hipEventRecord(e[0], s) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
     }
     for (int k = 0; k < 2; ++k) {
       if (!p->net[k].enabled) continue;
       PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
-      if (fuse_gea && k == first && cap_edge(e[0], s, c.a) != PF_OK) return PF_ERR_HIP;
+      if (fuse_gea && k == first && hipEventRecord(e[0], s) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
     }
-    PF_TRY(pf_launch_node_gradu(p, 1, c.a), "node_gradu");
-    if (cap_edge(e[1], c.a, c.b) != PF_OK) return PF_ERR_HIP;
     PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
     PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
-    if (cap_edge(e[2], s, c.b) != PF_OK) return PF_ERR_HIP;
-    PF_TRY(pf_launch_finalize(p, 0, 0, c.b), "finalize");
-    if (hipEventRecord(e[3], c.b) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    if (hipEventRecord(e[2], s) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    // branch A (created after the main chain's nodes of this iteration): gradu behind the last reader of u
+    if (hipStreamWaitEvent(c.a, e[0], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    PF_TRY(pf_launch_node_gradu(p, 1, c.a), "node_gradu");
+    if (hipEventRecord(e[1], c.a) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    if (!late_fin) {
+      int rc = capture_finalize(i);
+      if (rc != PF_OK) return rc;
+    }
+  }
+  if (late_fin) {
+    int rc = capture_finalize(iters - 1);
+    if (rc != PF_OK) return rc;
   }
   // join: finalize of the last iteration is behind everything else
   if (hipStreamWaitEvent(s, c.ev[PF_CAP_EV * (iters - 1) + 3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");

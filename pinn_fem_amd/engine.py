@@ -133,8 +133,10 @@ class HipEngine:
         self.m_t = torch.zeros(max(self.n_theta, 1), **f32)
         self.v_t = torch.zeros(max(self.n_theta, 1), **f32)
         self.theta_pad = torch.zeros(max(self.pad_total, 1), **f32)
-        self.prop_e = torch.zeros(ne, **f32)
-        self.prop_a = torch.zeros(ne, **f32)
+        # two halves: the iteration graph ping-pongs between them (pf_problem.prop_double); everything else
+        # uses the first
+        self.prop_e = torch.zeros(2 * ne, **f32)
+        self.prop_a = torch.zeros(2 * ne, **f32)
         self.g_f = torch.zeros(nd, **f32)
         self.g_ea = torch.zeros(ne, **f32)
         self.grad_u = torch.zeros(nd, **f32)
@@ -215,6 +217,7 @@ class HipEngine:
         P.n_shared, P.n_iface = self.n_shared, self.n_iface
         P.iface_elems = self.iface_elems.data_ptr() if self.n_iface_elems else None
         P.n_iface_elems = self.n_iface_elems
+        P.prop_double = 1
         self._configured = True
 
     def _ref(self):
