@@ -27,6 +27,14 @@ def main():
         parsed = product_example(kind, theta0 if theta0 else None)
         md = parsed["measured_data"]
         res = solve(parsed["model"], parsed["solver_config"], md.get("values"), md.get("dofs"))
+    elif kind == "warren":  # the 19-element Warren truss fixture (E and A nets), 20 iterations: a shared node with
+        # several incident elements on both sides, i.e. more than one interface element per shared node
+        rec = load_npz("step_warren_EA.npz")
+        model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, None),
+                              (2.0, 0.5, 1.0), theta_from(rec))
+        cfg = SolverConfig(max_iterations=20, learning_rate_u=1e-3, learning_rate_theta=5e-4, tolerance=1e-12)
+        res = solve_gd(model, cfg, rec["meas_vals"], rec["meas_dofs"], target_load_factor=0.7,
+                       u_initial=torch.from_numpy(rec["u"]))
     else:  # a 300-element chain, 25 iterations from the fixture state
         rec = load_npz("step_chain300_ex4shape.npz")
         model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, 10),

@@ -362,6 +362,24 @@ def test_sharded_hip_chain_matches_single_engine(tmp_path):
         assert rel_err(got["theta"][k], v.reshape(-1)) < 2e-5, k
 
 
+def test_sharded_hip_warren_truss_matches_single_engine(tmp_path):
+    """The 19-element Warren truss cut in two (2 ranks on one GPU, gloo): shared nodes carry several elements on
+    each side, so phase A evaluates more than one interface element per shared node; 20 iterations == one engine."""
+    from pinn_fem_amd.fem.solver import SolverConfig, solve_gd
+    got = _run_hip_ranks("warren", 2, tmp_path, 29633)
+    rec = load_npz("step_warren_EA.npz")
+    model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, None),
+                          (2.0, 0.5, 1.0), theta_from(rec))
+    cfg = SolverConfig(max_iterations=20, learning_rate_u=1e-3, learning_rate_theta=5e-4, tolerance=1e-12)
+    ref = solve_gd(model, cfg, rec["meas_vals"], rec["meas_dofs"], target_load_factor=0.7,
+                   u_initial=torch.from_numpy(rec["u"]))
+    assert got["n_history"] == 20
+    assert rel_err(got["u"], ref.displacements.flatten()) < 2e-5
+    assert rel_err(got["loss"], [h["loss_total"] for h in ref.history]) < 1e-4
+    for k, v in ref.nn_parameters.items():
+        assert rel_err(got["theta"][k], v.reshape(-1)) < 2e-5, k
+
+
 def test_api_pinn_gd_identifies_stiffness(tmp_path):
     """api_pinn_gradient_descent.py end to end on the GPU: a 3-bar chain whose measured displacements
     correspond to E*A = 2; the identified product must move from the initial guess (1) towards 2 and
