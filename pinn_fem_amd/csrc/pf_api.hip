@@ -327,6 +327,9 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
 // (properties, g_f, partial sums): everything that changes solver state (both Adam kernels, finalize)
 // is ordered behind finalize(t) and returns at once, so the final state is the reference's `break`.
 #define PF_CAP_EV 6
+// below this many elements the kernels are too short to hide anything behind: the branches' fork/join cost
+// (~5 us each against ~1.5 us for a plain boundary) would only add to a launch-bound iteration
+#define PF_GRAPH_DAG_MIN_ELEMS 200000   /* measured crossover between 1e5 (chain 0.061 vs DAG 0.067 ms) and 3e5 (0.099 vs 0.092) */
 struct pf_capture {
   hipStream_t s, a, b;
   hipEvent_t* ev;   // PF_CAP_EV per iteration: u readers done | gradu done | theta done | finalize done | forward fork | join
@@ -341,7 +344,10 @@ static int cap_edge(hipEvent_t e, hipStream_t from, hipStream_t to) {
 static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_capture& c) {
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
   hipStream_t s = c.s;
-  if (!any_net) {
+  // PF_GRAPH_SERIAL=1: experiment knob, the plain chain of launches inside the graph (no branches)
+  static const int serial_knob = getenv("PF_GRAPH_SERIAL") ? atoi(getenv("PF_GRAPH_SERIAL")) : -1;
+  const bool serial = serial_knob >= 0 ? serial_knob != 0 : p->mesh.n_elems < PF_GRAPH_DAG_MIN_ELEMS;
+  if (!any_net || serial) {
     for (int i = 0; i < iters; ++i) {
       int rc = enqueue_iteration(p, 1, 0, s, nullptr);
       if (rc != PF_OK) return rc;
