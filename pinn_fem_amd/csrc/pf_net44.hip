@@ -175,106 +175,6 @@ __device__ __forceinline__ float mlp_forward44(const float (&wv)[NV], const floa
   return (ao[0] + ao[1]) + (ao[2] + ao[3]);
 }
 
-// T independent element batches per wave through the net together: every phase is T times longer, so the
-// MFMA <-> VALU switches of the shared f32 pipe (PF_PHASE) are paid once per T*64 elements.
-template <int L, int IN, int NV, int T>
-__device__ __forceinline__ void mlp_forward44_multi(const float (&wv)[NV], const float (&wo)[HP + 1],
-                                                    const float (&x)[T][4], float (&h)[T][L][HP], float (&z)[T]) {
-  using W = WIdx<L>;
-  {
-    f32x4 acc[T][NB];
-    sfor<0, T>([&](auto t) {
-      constexpr int TT = t;
-      sfor<0, NB>([&](auto jb) {
-        constexpr int JB = jb;
-        acc[TT][JB] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[TT][JB] = MFMA44(W::f1(JB, IN), 1.0f, acc[TT][JB]);
-      });
-    });
-    sfor<0, IN>([&](auto c) {
-      constexpr int C = c;
-      sfor<0, T>([&](auto t) {
-        constexpr int TT = t;
-        sfor<0, NB>([&](auto jb) { constexpr int JB = jb; acc[TT][JB] = MFMA44(W::f1(JB, C), x[TT][C], acc[TT][JB]); });
-      });
-    });
-    PF_PHASE();
-    sfor<0, T>([&](auto t) {
-      constexpr int TT = t;
-      sfor<0, NB>([&](auto jb) {
-        constexpr int JB = jb;
-        sfor<0, 4>([&](auto r) { constexpr int R = r; h[TT][0][4 * JB + R] = pf_tanh(acc[TT][JB][R]); });
-      });
-    });
-    PF_PHASE();
-  }
-  sfor<2, L + 1>([&](auto l) {
-    constexpr int LL = l;
-    f32x4 acc[T][NB];
-    sfor<0, T>([&](auto t) {
-      constexpr int TT = t;
-      sfor<0, NB>([&](auto jb) {
-        constexpr int JB = jb;
-        acc[TT][JB] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[TT][JB] = MFMA44(W::fh(LL, JB, HP), 1.0f, acc[TT][JB]);
-      });
-    });
-    sfor<0, HP>([&](auto k) {
-      constexpr int K = k;
-      sfor<0, T>([&](auto t) {
-        constexpr int TT = t;
-        sfor<0, NB>([&](auto jb) { constexpr int JB = jb; acc[TT][JB] = MFMA44(W::fh(LL, JB, K), h[TT][LL - 2][K], acc[TT][JB]); });
-      });
-    });
-    PF_PHASE();
-    sfor<0, T>([&](auto t) {
-      constexpr int TT = t;
-      sfor<0, NB>([&](auto jb) {
-        constexpr int JB = jb;
-        sfor<0, 4>([&](auto r) { constexpr int R = r; h[TT][LL - 1][4 * JB + R] = pf_tanh(acc[TT][JB][R]); });
-      });
-    });
-    PF_PHASE();
-  });
-  sfor<0, T>([&](auto t) {
-    constexpr int TT = t;
-    float ao[4];
-    ao[0] = wo[HP];
-    ao[1] = ao[2] = ao[3] = 0.f;
-    sfor<0, HP>([&](auto k) { constexpr int K = k; ao[(K + 1) % 4] = fmaf(wo[K], h[TT][L - 1][K], ao[(K + 1) % 4]); });
-    z[TT] = (ao[0] + ao[1]) + (ao[2] + ao[3]);
-  });
-  PF_PHASE();
-}
-
-template <int L, int IN, int T>
-__global__ __launch_bounds__(256) void k_net44_forward_multi(pf_problem P, int which) {
-  const pf_net net = P.net[which];
-  const float* __restrict__ w = P.theta_pad + net.pad_off;
-  float* __restrict__ out = which == 0 ? P.prop_e : P.prop_a;
-  constexpr int NV = WIdx<L>::NV_FWD;
-  float wv[NV];
-  load_weights<NV, L>(wv, w, threadIdx.x & 63);
-  float wo[HP + 1];
-  load_out_weights(wo, w, L);
-  if (P.state->done) return;
-  const int n = P.mesh.n_elems;
-  for (int base = blockIdx.x * (blockDim.x * T); base < n; base += gridDim.x * (blockDim.x * T)) {
-    float x[T][4], h[T][L][HP], z[T];
-    sfor<0, T>([&](auto t) {
-      constexpr int TT = t;
-      const int e = base + TT * (int)blockDim.x + (int)threadIdx.x;
-      load_input44<IN>(x[TT], P.mesh.ecent, e, P.lam, e < n);
-    });
-    mlp_forward44_multi<L, IN, NV, T>(wv, wo, x, h, z);
-    sfor<0, T>([&](auto t) {
-      constexpr int TT = t;
-      const int e = base + TT * (int)blockDim.x + (int)threadIdx.x;
-      if (e < n) out[e] = (net.positive ? pf_softplus(z[TT]) : z[TT]) * net.scale;
-    });
-  }
-}
-
 // ---- forward kernel --------------------------------------------------------------------------------
 template <int L, int IN>
 __global__ __launch_bounds__(256) void k_net44_forward(pf_problem P, int which) {
@@ -631,14 +531,6 @@ int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
   // the blocks resident per CU
   static const int cap = getenv("PF_FWD_BLOCKS") ? atoi(getenv("PF_FWD_BLOCKS")) : 2048;
   static const int ldsb = getenv("PF_FWD_LDS") ? atoi(getenv("PF_FWD_LDS")) : 0;
-  static const int fwd_t = getenv("PF_FWD_T") ? atoi(getenv("PF_FWD_T")) : 1;
-  if (fwd_t == 2 && L <= 2) {
-    nb = (n + 511) / 512;
-    if (nb > cap) nb = cap;
-    if (nb < 1) nb = 1;
-    hipLaunchKernelGGL((k_net44_forward_multi<L, IN, 2>), dim3(nb), dim3(256), ldsb, s, *p, which);
-    return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
-  }
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL((k_net44_forward<L, IN>), dim3(nb), dim3(256), ldsb, s, *p, which);
