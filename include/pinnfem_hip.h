@@ -308,6 +308,10 @@ int pf_pcg_begin(const pf_problem* p, const double* b, double* x, double* ws, do
 /* n_iter CG iterations (no-ops after the stop test fired).  state_out: host double[4] or NULL =
  * [iterations done, stopped (0/1), |r|^2, |b|^2], read back after a stream synchronisation. */
 int pf_pcg_iterations(const pf_problem* p, double* x, double* ws, int n_iter, double* state_out, void* stream);
+/* the same n_iter iterations captured as one hipGraph (handle for pf_graph_launch / pf_graph_destroy), and the
+ * state read-back on its own */
+int pf_pcg_graph_create(const pf_problem* p, double* x, double* ws, int n_iter, void* stream, void** graph_out);
+int pf_pcg_state(const pf_problem* p, double* ws, double* state_out, void* stream);
 
 /* ---- extensions (off the default path) ------------------------------------------------ */
 /* generic Adam (torch.optim.Adam single-tensor arithmetic) on a flat vector */

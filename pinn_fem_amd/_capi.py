@@ -127,6 +127,8 @@ SYMBOLS = {
     "pf_pcg_workspace_count": (C.c_longlong, [_PP]),
     "pf_pcg_begin": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "pf_pcg_iterations": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_void_p]),
+    "pf_pcg_graph_create": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pf_pcg_state": (C.c_int, [_PP, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "pf_comm_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
     "pf_comm_create": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pf_comm_destroy": (C.c_int, [C.c_void_p]),

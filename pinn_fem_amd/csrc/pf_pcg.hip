@@ -220,15 +220,11 @@ int pf_pcg_begin(const pf_problem* p, const double* b, double* x, double* ws, do
   return PF_OK;
 }
 
-// n_iter CG iterations (no-ops once the stop test |r| <= rtol |b| fired); state_out (host, may be NULL)
-// receives [iterations, done, |r|^2, |b|^2] after a stream synchronisation
-int pf_pcg_iterations(const pf_problem* p, double* x, double* ws, int n_iter, double* state_out, void* stream) {
-  if (!p || !x || !ws || n_iter < 0) { pf_set_error("pf_pcg_iterations: bad argument"); return PF_ERR_ARG; }
+static int pcg_enqueue(const pf_problem* p, double* x, double* ws, int n_iter, hipStream_t s) {
   const int n = p->mesh.n_dofs, nb = pf_node_blocks(p->mesh.n_nodes);
   double *r = ws, *z = ws + n, *pp = ws + 2 * (size_t)n, *ap = ws + 3 * (size_t)n, *dinv = ws + 4 * (size_t)n;
   double* part = ws + 5 * (size_t)n;
   double* st = part + 2 * PF_NODE_SLOTS;
-  hipStream_t s = (hipStream_t)stream;
   int nbv = (n + 255) / 256;
   if (nbv > PF_MAX_NODE_BLOCKS) nbv = PF_MAX_NODE_BLOCKS;
   for (int it = 0; it < n_iter; ++it) {
@@ -240,15 +236,62 @@ int pf_pcg_iterations(const pf_problem* p, double* x, double* ws, int n_iter, do
     hipLaunchKernelGGL(k_pcg_dir, dim3(nbv), dim3(256), 0, s, st, n, z, pp);
   }
   PCG_CHECK("pf_pcg_iterations");
-  if (state_out) {
-    double h[ST_COUNT];
-    if (hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-      pf_set_error("pf_pcg_iterations: state read-back failed");
-      return PF_ERR_HIP;
-    }
-    state_out[0] = h[ST_ITERS]; state_out[1] = h[ST_DONE]; state_out[2] = h[ST_RR]; state_out[3] = h[ST_BB];
-  }
   return PF_OK;
+}
+
+static int pcg_read_state(double* ws, int n, double* state_out, hipStream_t s) {
+  double* st = ws + 5 * (size_t)n + 2 * PF_NODE_SLOTS;
+  double h[ST_COUNT];
+  if (hipMemcpyAsync(h, st, sizeof(h), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+    pf_set_error("pf_pcg: state read-back failed");
+    return PF_ERR_HIP;
+  }
+  state_out[0] = h[ST_ITERS]; state_out[1] = h[ST_DONE]; state_out[2] = h[ST_RR]; state_out[3] = h[ST_BB];
+  return PF_OK;
+}
+
+// n_iter CG iterations (no-ops once the stop test |r| <= rtol |b| fired); state_out (host, may be NULL)
+// receives [iterations, done, |r|^2, |b|^2] after a stream synchronisation
+int pf_pcg_iterations(const pf_problem* p, double* x, double* ws, int n_iter, double* state_out, void* stream) {
+  if (!p || !x || !ws || n_iter < 0) { pf_set_error("pf_pcg_iterations: bad argument"); return PF_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = pcg_enqueue(p, x, ws, n_iter, s);
+  if (rc != PF_OK) return rc;
+  return state_out ? pcg_read_state(ws, p->mesh.n_dofs, state_out, s) : PF_OK;
+}
+
+// the same n_iter iterations as ONE hipGraph (record and pointers baked in; handle for pf_graph_launch /
+// pf_graph_destroy): 5 tiny launches per CG iteration are launch bound when issued one by one
+int pf_pcg_graph_create(const pf_problem* p, double* x, double* ws, int n_iter, void* stream, void** graph_out) {
+  if (!p || !x || !ws || n_iter < 1 || !graph_out) { pf_set_error("pf_pcg_graph_create: bad argument"); return PF_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    pf_set_error("pf_pcg_graph_create: hipStreamBeginCapture failed");
+    return PF_ERR_HIP;
+  }
+  const int rc = pcg_enqueue(p, x, ws, n_iter, s);
+  const hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != PF_OK || e != hipSuccess || !graph) {
+    if (graph) hipGraphDestroy(graph);
+    if (rc == PF_OK) pf_set_error("pf_pcg_graph_create: capture failed");
+    return rc != PF_OK ? rc : PF_ERR_HIP;
+  }
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    hipGraphDestroy(graph);
+    pf_set_error("pf_pcg_graph_create: hipGraphInstantiate failed");
+    return PF_ERR_HIP;
+  }
+  hipGraphDestroy(graph);
+  *graph_out = (void*)exec;
+  return PF_OK;
+}
+
+// [iterations, stopped, |r|^2, |b|^2] of the running solve (synchronises the stream)
+int pf_pcg_state(const pf_problem* p, double* ws, double* state_out, void* stream) {
+  if (!p || !ws || !state_out) { pf_set_error("pf_pcg_state: bad argument"); return PF_ERR_ARG; }
+  return pcg_read_state(ws, p->mesh.n_dofs, state_out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -393,16 +393,29 @@ class HipEngine:
         _capi.check(self.lib.pf_pcg_begin(self._ref(), bb.data_ptr(), x.data_ptr(), ws.data_ptr(), float(rtol), s),
                     "pf_pcg_begin")
         if max_iter is None:
-            max_iter = 3 * n + 50
+            max_iter = 40 * n + 2000            # slender trusses are beam-like: CG needs far more than n steps
         st = (C.c_double * 4)()
         done_it = 0
-        while True:
-            k = min(poll, max_iter - done_it)
-            _capi.check(self.lib.pf_pcg_iterations(self._ref(), x.data_ptr(), ws.data_ptr(), int(max(k, 0)), st, s),
-                        "pf_pcg_iterations")
-            done_it += max(k, 0)
-            if st[1] != 0.0 or done_it >= max_iter:
-                break
+        graph = C.c_void_p()
+        use_graph = os.environ.get("PINNFEM_GRAPH", "1") != "0" and max_iter >= poll
+        if use_graph:
+            _capi.check(self.lib.pf_pcg_graph_create(self._ref(), x.data_ptr(), ws.data_ptr(), int(poll), s,
+                                                     C.byref(graph)), "pf_pcg_graph_create")
+        try:
+            while True:
+                k = min(poll, max_iter - done_it)
+                if use_graph and k == poll:
+                    _capi.check(self.lib.pf_graph_launch(graph, s), "pf_graph_launch")
+                    _capi.check(self.lib.pf_pcg_state(self._ref(), ws.data_ptr(), st, s), "pf_pcg_state")
+                else:
+                    _capi.check(self.lib.pf_pcg_iterations(self._ref(), x.data_ptr(), ws.data_ptr(), int(max(k, 0)), st, s),
+                                "pf_pcg_iterations")
+                done_it += max(k, 0)
+                if st[1] != 0.0 or done_it >= max_iter:
+                    break
+        finally:
+            if graph:
+                self.lib.pf_graph_destroy(graph)
         converged = st[2] <= (rtol * rtol) * st[3] * 4.0 or st[3] == 0.0     # |r| <= 2 rtol |b|
         return x, int(st[0]), bool(converged), float(st[2]), float(st[3])
 

@@ -316,7 +316,10 @@ def solve_nr(model, config=None, target_load_factor=1.0, u_initial=None) -> Solv
         max_e = _max_abs_strain(model, u)
         rhs = f_ext - eng.kv_f64(u)
         du, _, ok, rr, bb = eng.pcg_solve(rhs)
-        if not ok or not np.isfinite(rr):
+        # np.linalg.solve either succeeds or raises on a singular matrix; CG shows singularity (or a hopeless
+        # condition number for the Jacobi preconditioner) as a residual that does not come down at all.  An
+        # inner solve that merely stops short of 1e-13 is fine: the Newton loop then acts as iterative refinement.
+        if not np.isfinite(rr) or (not ok and rr > 1e-4 * bb):
             raise RuntimeError("Tangent stiffness became singular during solve")
         u = u + du
         residual_norm = float(torch.linalg.norm(du)) / max(float(torch.linalg.norm(u)), config.min_denominator)
