@@ -132,6 +132,7 @@ SYMBOLS = {
     "pf_comm_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
     "pf_comm_create": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pf_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pf_shard_iterations": (C.c_int, [_PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
     "pf_shard_graph_create": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

@@ -102,6 +102,17 @@ static int all_reduce(pf_comm* c, float* buf, size_t n, hipStream_t s) {
   return PF_OK;
 }
 
+}  // extern "C" (re-opened below)
+extern "C" {
+// sum over ranks of buf[0..n), in place, on `stream`: the driver's collective on its own (the host checks it
+// against torch.distributed's result before trusting the communicator)
+int pf_comm_all_reduce(void* comm, float* buf, int n, void* stream) {
+  if (!comm || !buf || n < 0) return comm_fail(PF_ERR_ARG, "pf_comm_all_reduce", "bad argument");
+  return all_reduce((pf_comm*)comm, buf, (size_t)n, (hipStream_t)stream);
+}
+}
+extern "C" {
+
 #define PF_RUN(expr)          \
   do {                        \
     int rc__ = (expr);        \

@@ -218,9 +218,23 @@ def rccl_comm(backend, group=None):
         ok = 1 if rc == 0 else 0
     else:
         ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) != 1:
+    def all_ok(v):      # collective: 1 only if every rank says 1
+        flag = torch.tensor([v], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item())
+
+    ok = all_ok(ok)
+    if ok:
+        # trust, but verify: the communicator's all-reduce must give what torch.distributed's gives
+        # (small integers: the sum is exact whatever the reduction order)
+        probe = (torch.arange(16, dtype=torch.float32, device=dev) + 1.0) * float(rank + 1)
+        want = probe.clone()
+        dist.all_reduce(want, group=group)
+        s = torch.cuda.current_stream(dev)
+        rc = lib.pf_comm_all_reduce(comm, probe.data_ptr(), probe.numel(), s.cuda_stream)
+        s.synchronize()
+        ok = all_ok(1 if (rc == 0 and bool(torch.equal(probe, want))) else 0)
+    if ok != 1:
         if comm.value:
             lib.pf_comm_destroy(comm)
         if rank == 0 and os.environ.get("PINNFEM_QUIET", "0") != "1":
