@@ -31,6 +31,7 @@ def _sources():
     units += [(f"pf_net44_{w}.o", "pf_net44.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
               for w in reversed(WIDTHS)]
     units += [(f"pf_net_{w}.o", "pf_net.hip", [f"-DPF_HP={w}"]) for w in WIDTHS]
+    units += [(f"pf_net16_{w}.o", "pf_net16.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]) for w in WIDTHS]
     return units
 
 

@@ -96,7 +96,12 @@ static int check_problem(const pf_problem* p) {
   }                                                               \
   return fail(PF_ERR_UNSUPPORTED, "net width outside 1..32");
 
+static int net_forward16(const pf_problem* p, int which, hipStream_t s) { PF_WIDTH_SWITCH(pf_launch_net16_forward_) }
+
 static int net_forward(const pf_problem* p, int which, hipStream_t s) {
+  // PF_FWD_F16=1: the split-f16 forward kernel (pf_net16.hip) in place of the 4x4x1 f32 one
+  static const bool fwd16 = getenv("PF_FWD_F16") && atoi(getenv("PF_FWD_F16")) != 0;
+  if (p->wg_mode == PF_WG_MFMA44 && fwd16) return net_forward16(p, which, s);
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_forward_) }
   PF_WIDTH_SWITCH(pf_launch_net_forward_)
 }
