@@ -103,26 +103,26 @@ __global__ __launch_bounds__(256) void k_net16_forward(pf_problem P, int which) 
   const int waves = blockDim.x >> 6;
   const int stride = gridDim.x * waves * 32;
   int base = (blockIdx.x * waves + wvid) * 32;                // wave-uniform
+  // Lanes past the end work on the LAST element again (same inputs, same value, a redundant store of identical
+  // bits), and both half-waves store the result: no exec-masked branch is left in the loop, so the compiler's
+  // vmcnt accounting is exact and the wait for the next pass's inputs does not also wait for this pass's store.
   auto fetch = [&](float (&xx)[4], int ee) {
-    xx[0] = xx[1] = xx[2] = xx[3] = 0.f;
-    if (ee < n) {
-      xx[0] = P.lam;
-      if (IN == 3) {
-        const float2 c = reinterpret_cast<const float2*>(P.mesh.ecent)[ee];
-        xx[1] = c.x; xx[2] = c.y;
-      } else {
-        xx[1] = P.mesh.ecent[ee];
-      }
+    const int ec = ee < n ? ee : n - 1;
+    xx[0] = P.lam; xx[1] = xx[2] = xx[3] = 0.f;
+    if (IN == 3) {
+      const float2 c = reinterpret_cast<const float2*>(P.mesh.ecent)[ec];
+      xx[1] = c.x; xx[2] = c.y;
+    } else {
+      xx[1] = P.mesh.ecent[ec];
     }
   };
   float xn[4];
   fetch(xn, base + nn);                                       // first pass's inputs leave with the weights
-  if (P.state->done) return;
+  if (P.state->done || n <= 0) return;
   for (; base < n; base += stride) {
-    const int e = base + nn;
-    const bool live = e < n;
+    const int e = base + nn < n ? base + nn : n - 1;
     float x[4] = {xn[0], xn[1], xn[2], xn[3]};
-    if (base + stride < n) fetch(xn, e + stride);             // next pass's inputs one pass ahead
+    fetch(xn, base + stride + nn);                            // next pass's inputs one pass ahead (clamped)
     __builtin_amdgcn_sched_barrier(0);
     // ---- layer 1 on the vector ALU, the reference's order: bias, then the inputs ascending --------------------
     float h[UH];
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_net16_forward(pf_problem P, int which) 
     float part = 0.f;
     sfor<0, UH>([&](auto r) { constexpr int R = r; part = fmaf(wo[R], h[R], part); });
     const float z = (part + __shfl_xor(part, 32, 64)) + bo;
-    if (live && hw == 0) out[e] = (net.positive ? pf_softplus(z) : z) * net.scale;
+    out[e] = (net.positive ? pf_softplus(z) : z) * net.scale;
   }
 }
 
@@ -171,7 +171,7 @@ template <int L, int IN>
 int launch_fwd16(const pf_problem* p, int which, hipStream_t s) {
   const int n = p->mesh.n_elems;
   int nb = (n + 127) / 128;                    // 4 waves x 32 elements per block pass
-  static const int cap = getenv("PF_FWD16_BLOCKS") ? atoi(getenv("PF_FWD16_BLOCKS")) : 2048;
+  static const int cap = getenv("PF_FWD16_BLOCKS") ? atoi(getenv("PF_FWD16_BLOCKS")) : 512;
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL((k_net16_forward<L, IN>), dim3(nb), dim3(256), 0, s, *p, which);
