@@ -790,3 +790,39 @@ assert rel(E, Eo) < 2e-6 and rel(A, Ao) < 2e-6
     env = dict(os.environ, PF_FWD_F16="1", PINNFEM_QUIET="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_cli_one_dimensional_list_format_json(tmp_path):
+    """`generic.py` on a dimension-1 problem in the list format (nodes [[x], ...], elements [[i, j], ...], explicit
+    fixed_dofs; examples/json/generic.py:155-192): classical FEM (auto -> Newton-Raphson) and a PINN-GD run with an
+    E = NN(load_factor, x) net, against the oracle on the same inputs."""
+    from pinn_fem_amd.cli import generic as g
+    xs = [0.0, 1.0, 2.5, 3.0, 4.5]
+    base = {"nodes": [[x] for x in xs], "elements": [[0, 1], [1, 2], [2, 3], [3, 4]], "fixed_dofs": [0],
+            "loads": [0.0, 0.0, 0.5, 0.0, 1.0], "material": {"young": 2.0, "area": 0.5, "density": 1.0}}
+    # (1) classical FEM
+    p1 = tmp_path / "bar1d_fem.json"
+    p1.write_text(json.dumps(dict(base, solver_type="fem", solver_config={"n_increments": 2, "tolerance": 1e-10})))
+    out = g.solve_problem(g.parse_problem(str(p1)))
+    pb = orc.Problem(nodes=np.array(xs), elements=np.array(base["elements"]), loads=np.array(base["loads"]),
+                     fixed_dofs=np.array([0]), dimension=1, young=2.0, area=0.5, density=1.0)
+    ref = orc.solve(pb, orc.SolverConfig(method="nr", n_increments=2, tolerance=1e-10))
+    assert out["converged"] and rel_err(np.array(out["displacements"]).reshape(-1), ref.displacements.reshape(-1)) < 1e-6
+    # (2) PINN-GD with a net on E: 40 iterations per increment from the same initial parameters
+    p2 = tmp_path / "bar1d_gd.json"
+    meas = {"global_dof": [1, 2, 3, 4], "measured_u": [0.4, 1.0, 1.2, 1.9]}
+    p2.write_text(json.dumps(dict(base, solver_type="pinn-gd", measured_displacements=meas,
+                                  nn_config={"young": {"enabled": True, "hidden_layers": 2, "neurons_per_layer": 12,
+                                                       "input_dim": 2}},
+                                  solver_config={"n_increments": 2, "max_iterations": 40, "tolerance": 1e-30,
+                                                 "learning_rate_u": 0.01, "learning_rate_theta": 1e-3})))
+    torch.manual_seed(5)
+    parsed = g.parse_problem(str(p2))
+    theta = [p.detach().cpu().numpy().copy() for p in parsed["model"].material.get_all_torch_params()]
+    out2 = g.solve_problem(parsed)
+    pb2 = orc.Problem(nodes=np.array(xs), elements=np.array(base["elements"]), loads=np.array(base["loads"]),
+                      fixed_dofs=np.array([0]), dimension=1, young=orc.NetParams([t.copy() for t in theta], 2.0),
+                      area=0.5, density=1.0, measured_vals=np.array(meas["measured_u"]), measured_dofs=np.array(meas["global_dof"]))
+    ref2 = orc.solve(pb2, orc.SolverConfig(method="gd", n_increments=2, max_iterations=40, tolerance=1e-30,
+                                           learning_rate_u=0.01, learning_rate_theta=1e-3))
+    assert rel_err(np.array(out2["displacements"]).reshape(-1), ref2.displacements.reshape(-1)) < 1e-5
