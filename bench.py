@@ -108,7 +108,8 @@ def side_config(workload, n_elems, dev, steps, mesh="chain"):
                        learning_rate_theta=5e-4 if workload == "ex4" else 1e-3)
     eng = HipEngine(model, mv, md, device=dev)
     eng.begin(None, 0.1, cfg, want_history=False)
-    eng.iterate(10)
+    eng.prepare_graph()
+    eng.iterate(eng.GRAPH_ITERS)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     eng.iterate(steps)
@@ -116,6 +117,20 @@ def side_config(workload, n_elems, dev, steps, mesh="chain"):
     dt = time.perf_counter() - t0
     return {"value": n_elems * steps / dt, "unit": "element-evals/s", "ms_per_step": dt / steps * 1e3,
             "steps": steps}
+
+
+def launch_workers(n: int) -> int:
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -130,6 +145,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks here, as fresh child processes, BEFORE anything
+        # in this process has touched the GPU (no torch import yet); this process only relays the exit code
+        return launch_workers(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -158,26 +178,34 @@ def main():
 
     n_local = args.elems
     lr_t = 5e-4 if args.workload == "ex4" else 1e-3
-    cfg = SolverConfig(max_iterations=args.warmup + 2 * args.steps + 8, tolerance=0.0, learning_rate_u=0.01,
+    cfg = SolverConfig(max_iterations=args.warmup + 2 * args.steps + 32, tolerance=0.0, learning_rate_u=0.01,
                        learning_rate_theta=lr_t, alpha_physics=1.0, alpha_data=100.0)
     if world == 1:
         from pinn_fem_amd.engine import HipEngine
         model, mv, md, widths = build_model(n_local, args.workload)
         eng = HipEngine(model, mv, md, device=dev)
         eng.begin(None, 0.1, cfg, want_history=False)
+        eng.prepare_graph()                           # capture + instantiate: never inside the timed region
+        gk = eng.GRAPH_ITERS
+        n_warm = ((max(args.warmup, 1) + gk - 1) // gk) * gk   # >= W, whole replays: the graph is uploaded and hot
         run_warm = lambda n: eng.iterate(n)
         run_timed = lambda n: eng.iterate(n)          # hipGraph replay (10 iterations per graph)
         run_events = lambda n: eng.iterate_timed(n)   # eager launches with HIP events around every kernel
+        graph_count = lambda: eng.graph_creates
     else:
         from pinn_fem_amd.dist import ShardedChainEngine
         widths = {"ex4": (20, 15, 10), "ex3": (20, None, None)}[args.workload]
         eng = ShardedChainEngine(n_local, args.workload, rank, world, dev)
         eng.begin(None, 0.1, cfg)
+        eng.prepare()                                 # the C driver's RCCL communicator (collective)
+        n_warm = max(args.warmup, 1)
         run_warm = lambda n: eng.iterate(n)
         run_timed = lambda n: eng.iterate(n)
         run_events = lambda n: eng.iterate_timed(n)
+        graph_count = lambda: 0
 
-    run_warm(args.warmup)
+    run_warm(n_warm)
+    graphs_before = graph_count()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -194,7 +222,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st = eng.state()
-    assert st.iter == args.warmup + args.steps, (st.iter, args.warmup + args.steps)
+    assert st.iter == n_warm + args.steps, (st.iter, n_warm + args.steps)
+    assert graph_count() == graphs_before, "a hipGraph was captured inside the timed region"
     # the same K steps once more, launched eagerly with a HIP event before every kernel on the launch
     # stream: per-kernel durations for the roofline (not part of `value`)
     t1 = time.perf_counter()
@@ -241,7 +270,8 @@ def main():
             "metric": "element-residual-grad evals/sec (PINN+GD iteration: MLP fwd+bwd, stiffness, "
                       "assembly, residual, Adam), collinear truss",
             "value": value, "unit": "element-evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "warmup_iterations_run": n_warm, "graph_captured_before_timing": True,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic" + (" (ONE-GPU REHEARSAL: not a valid multi-GPU number)" if rehearsal else ""),
             "config": {"workload": f"{args.workload} shape (nets {widths}, E and A evaluated), "
@@ -252,6 +282,9 @@ def main():
             "kernel_ms": {n: float(m) for n, m in zip(names, slot_ms)},
             "roofline": roof,
         }
+        if world > 1:
+            from pinn_fem_amd.dist import shard_driver_info
+            out["config"].update(shard_driver_info(eng.backend))
         if world == 1 and not args.no_also:
             # BASELINE.json configs[1] (example3 shape, E = NN, 10^5 elements) for the record; the headline
             # `value` above stays the 10^6-element configuration the metric is quoted on
@@ -270,4 +303,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

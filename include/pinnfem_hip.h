@@ -290,6 +290,8 @@ int pf_shard_graph_create(const pf_problem* p, float* buf1, float* buf2, int wit
 int pf_comm_unique_id(const char* librccl_path, void* id_out);
 int pf_comm_create(const char* librccl_path, const void* id, int rank, int world, void** comm_out);
 int pf_comm_destroy(void* comm);
+/* rank and rank count as the communicator reports them (ncclCommUserRank, ncclCommCount) */
+int pf_comm_info(void* comm, int* rank_out, int* nranks_out);
 /* sum over ranks of buf[0..n), in place, on `stream` (the collective pf_shard_iterations issues, on its own) */
 int pf_comm_all_reduce(void* comm, float* buf, int n, void* stream);
 int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf1, float* buf2,

@@ -132,6 +132,7 @@ SYMBOLS = {
     "pf_comm_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
     "pf_comm_create": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pf_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pf_shard_iterations": (C.c_int, [_PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p]),
@@ -159,9 +160,16 @@ def load():
     # torch ships its own libamdhip64.so.7: import it first so that this library binds to the
     # SAME HIP runtime instance (two runtimes in one process see no device)
     import torch  # noqa: F401
+    from . import build as _build
+    if os.path.exists(LIB_PATH) and os.path.exists(_build.HIPCC) and os.environ.get("PINNFEM_NO_REBUILD", "0") != "1":
+        # an existing library older than any kernel source or the header is STALE: rebuild it rather than
+        # test or benchmark an old binary (build() returns at once when the library is up to date)
+        try:
+            _build.build(verbose=False)
+        except Exception as e:
+            raise PinnFemHipError(f"rebuilding the stale {LIB_PATH} failed: {e}") from e
     if not os.path.exists(LIB_PATH):
         # not a fallback: build the HIP library in-tree when a fresh checkout has none yet
-        from . import build as _build
         if not os.path.exists(_build.HIPCC):
             raise PinnFemHipError(
                 f"{LIB_PATH} not found and hipcc ({_build.HIPCC}) is not available: the HIP library "

@@ -8,6 +8,8 @@ keeps the compile parallel.
 """
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import subprocess
 import sys
@@ -18,6 +20,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "lib", "libpinnfem_hip.so")
+STAMP = os.path.join(HERE, "lib", "libpinnfem_hip.stamp")   # hash of everything the library was built from
 WIDTHS = (4, 8, 12, 16, 20, 24, 28, 32)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
@@ -35,16 +38,44 @@ def _sources():
     return units
 
 
-def _newest_input():
-    paths = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+def _input_paths():
+    paths = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     paths.append(os.path.join(ROOT, "include", "pinnfem_hip.h"))
+    return paths
+
+
+def inputs_hash() -> str:
+    """Content hash of every kernel source, the header and the compile recipe.  File times do not survive a
+    snapshot copy to another machine; contents do."""
+    h = hashlib.sha256()
+    for p in _input_paths():
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(repr((FLAGS[:4], [(u[0], u[1], u[2]) for u in _sources()])).encode())
+    return h.hexdigest()
+
+
+def up_to_date() -> bool:
+    try:
+        with open(STAMP) as f:
+            return os.path.exists(LIB) and f.read().strip() == inputs_hash()
+    except OSError:
+        return False
+
+
+def _newest_input(src):
+    """Newest of one unit's own source and the headers (every unit includes them)."""
+    paths = [os.path.join(CSRC, src)] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    paths.append(os.path.join(ROOT, "include", "pinnfem_hip.h"))
+    paths.append(os.path.abspath(__file__))      # the compile recipe
     return max(os.path.getmtime(p) for p in paths)
 
 
 def _compile(unit):
     obj, src, defs = unit
     out = os.path.join(OBJ, obj)
-    if os.path.exists(out) and os.path.getmtime(out) >= _newest_input():
+    if os.path.exists(out) and os.path.getmtime(out) >= _newest_input(src):
         return obj, 0, ""
     cmd = [HIPCC, *FLAGS, *defs, "-c", os.path.join(CSRC, src), "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -52,13 +83,22 @@ def _compile(unit):
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and up_to_date():
+        return LIB
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    # one builder at a time (several ranks of one job may find the library stale together)
+    with open(os.path.join(os.path.dirname(LIB), ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and up_to_date():
+            return LIB
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force: bool, verbose: bool) -> str:
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    if (not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_input()):
-        return LIB
     units = _sources()
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         for obj, rc, log in ex.map(_compile, units):
@@ -71,6 +111,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    with open(STAMP, "w") as f:
+        f.write(inputs_hash())
     if verbose:
         print(f"built {LIB}", file=sys.stderr)
     return LIB

@@ -359,13 +359,51 @@ def _init_distributed():
     return dist.get_rank(), world
 
 
+def _shutdown_distributed(failed: bool):
+    """Tear the sharded run down in order: device idle, the C driver's RCCL communicators, then torch's
+    process group.  After a rank-local failure the other ranks may sit in a collective this rank will
+    never join: abort the group (they fail fast) instead of a collective-free destroy that could hang."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if failed:
+            pg = dist.distributed_c10d._get_default_group()
+            for be_name in ("cuda", "cpu"):
+                try:
+                    be = pg._get_backend(torch.device(be_name))
+                    if hasattr(be, "abort"):
+                        be.abort()
+                except Exception:
+                    pass
+        from ..dist import destroy_rccl_comms
+        destroy_rccl_comms()
+    finally:
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     if len(argv) < 2:
         print("Usage: python generic.py problem.json [output.json]")
         sys.exit(1)
-    problem_file = argv[1]
     rank, world = _init_distributed()
+    failed = True
+    try:
+        _main_body(argv, rank, world)
+        failed = False
+    finally:
+        if world > 1:
+            _shutdown_distributed(failed)
+
+
+def _main_body(argv, rank, world):
+    problem_file = argv[1]
     if rank != 0:
         # non-zero ranks take part in the solve only: no log file, no result files
         try:

@@ -21,6 +21,8 @@ struct pf_comm {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommCount)(const ncclComm_t, int*);
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*);
   const char* (*GetErrorString)(ncclResult_t);
   ncclComm_t comm;
   int rank, world;
@@ -43,6 +45,8 @@ static int load_rccl(pf_comm* c, const char* path) {
   PF_SYM(CommInitRank, "ncclCommInitRank")
   PF_SYM(AllReduce, "ncclAllReduce")
   PF_SYM(CommDestroy, "ncclCommDestroy")
+  PF_SYM(CommCount, "ncclCommCount")
+  PF_SYM(CommUserRank, "ncclCommUserRank")
   PF_SYM(GetErrorString, "ncclGetErrorString")
 #undef PF_SYM
   return PF_OK;
@@ -81,6 +85,16 @@ int pf_comm_create(const char* librccl_path, const void* id, int rank, int world
   c->rank = rank;
   c->world = world;
   *comm_out = c;
+  return PF_OK;
+}
+
+// what the communicator itself reports (ncclCommUserRank / ncclCommCount), for the bench line
+int pf_comm_info(void* comm, int* rank_out, int* nranks_out) {
+  if (!comm || !rank_out || !nranks_out) return comm_fail(PF_ERR_ARG, "pf_comm_info", "bad argument");
+  pf_comm* c = (pf_comm*)comm;
+  ncclResult_t r = c->CommUserRank(c->comm, rank_out);
+  if (r == ncclSuccess) r = c->CommCount(c->comm, nranks_out);
+  if (r != ncclSuccess) return comm_fail(PF_ERR_HIP, "ncclCommCount", c->GetErrorString(r));
   return PF_OK;
 }
 

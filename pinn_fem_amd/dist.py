@@ -245,6 +245,43 @@ def rccl_comm(backend, group=None):
     return comm
 
 
+def shard_driver_info(backend, group=None) -> dict:
+    """Which driver runs this backend's iterations and what the communicator reports: for the bench line."""
+    out = {"shard_driver": getattr(backend, "driver_used", None), "comm_ranks": None, "comm_rank": None}
+    comm = _RCCL_COMMS.get(id(group))
+    if comm is not None:
+        import ctypes as C
+        r, n = C.c_int(-1), C.c_int(-1)
+        if backend.eng.lib.pf_comm_info(comm, C.byref(r), C.byref(n)) == 0:
+            out["comm_rank"], out["comm_ranks"] = int(r.value), int(n.value)
+    elif dist.is_initialized():
+        out["comm_ranks"] = dist.get_world_size(group)
+        out["comm_rank"] = dist.get_rank(group)
+    return out
+
+
+def broadcast_theta(flat: torch.Tensor, group=None, check: bool = True):
+    """Every rank takes rank 0's parameters (in place).  The sharded path REPLICATES theta and relies on the
+    replicas being bit-identical (every rank applies the same reduced gradient); networks built from an
+    unseeded torch RNG differ per process, so the replicas are made equal here, before anything is packed.
+    check: assert with a MIN/MAX all-reduce that they now are."""
+    if not dist.is_initialized() or dist.get_world_size(group) < 2 or flat.numel() == 0:
+        return
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    staged = flat.is_cuda and dist.get_backend(group) == "gloo"
+    h = flat.detach().cpu() if staged else flat.detach()
+    dist.broadcast(h, src=src, group=group)
+    if staged:
+        with torch.no_grad():
+            flat.copy_(h)
+    if check:
+        lo, hi = h.clone(), h.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if not bool(torch.equal(lo, hi)):
+            raise RuntimeError("theta differs between ranks after the broadcast")
+
+
 def destroy_rccl_comms():
     """Release the C driver's communicators (call before torch.distributed.destroy_process_group)."""
     lib = _capi.load()
@@ -265,6 +302,8 @@ def run_iterations(backend: ShardBackend, n_iter: int, group=None,
         bufs = getattr(backend, "bufs", None) or make_buffers(backend)
     eng = getattr(backend, "eng", None)
     comm = rccl_comm(backend, group) if n_iter > 0 else None
+    if n_iter > 0:
+        backend.driver_used = "c-rccl" if (comm is not None and backend.early_iface) else "python"
     if comm is not None and backend.early_iface:
         g0, g1 = backend.graphs()
         with eng.on_stream():
@@ -333,8 +372,12 @@ class HipShardBackend(ShardBackend):
         self._graphs = None                      # C driver only
 
     # -- solve_gd-level control ---------------------------------------------------------------------
-    def begin(self, u_initial_local, lam, config, want_history=True):
+    def begin(self, u_initial_local, lam, config, want_history=True, group=None):
         self._drop_graphs()
+        if self.eng.n_theta:
+            # replicas of theta must be bit-identical on every rank (see broadcast_theta)
+            with self.eng.on_stream():
+                broadcast_theta(self.eng.theta.flat, group)
         self.eng.begin(u_initial_local, lam, config, want_history=want_history)
         # grad_theta is reduced straight into buf2, where the second collective reads it
         self.eng.P.grad_theta = self.bufs[1].data_ptr() + 4 * self.n_iface
@@ -543,6 +586,11 @@ class ShardedChainEngine:
 
     def begin(self, u0, lam, config):
         self.backend.begin(u0, lam, config, want_history=False)
+
+    def prepare(self):
+        """Create the C driver's RCCL communicator (collective) ahead of the first iteration."""
+        comm = rccl_comm(self.backend)
+        self.backend.driver_used = "c-rccl" if (comm is not None and self.backend.early_iface) else "python"
 
     def iterate(self, n):
         run_iterations(self.backend, n, bufs=self.bufs)

@@ -253,21 +253,32 @@ class HipEngine:
             self.lib.pf_graph_destroy(g)
         self._graph = None
 
+    graph_creates = 0        # hipGraph captures + instantiations so far (bench.py asserts none is timed)
+
+    @_on_engine_stream
+    def prepare_graph(self):
+        """Capture and instantiate the iteration hipGraph of the current pf_problem record now (it is
+        otherwise created by the first iterate() call that replays it).  Enqueues no iteration."""
+        if getattr(self, "_graph", None) is None:
+            g = C.c_void_p()
+            _capi.check(self.lib.pf_graph_create(self._ref(), self.GRAPH_ITERS, self._stream(), C.byref(g)),
+                        "pf_graph_create")
+            self._graph = g
+            self.graph_creates += 1
+
     @_on_engine_stream
     def iterate(self, n_iter: int, use_graph: Optional[bool] = None):
         """Enqueue n_iter GD iterations.  Whole multiples of GRAPH_ITERS replay a captured hipGraph
-        (created lazily per begin(); the graph bakes in the current pf_problem record), the remainder
-        is launched eagerly.  Launches after the device-side stop are no-ops either way."""
+        (created lazily per begin(), or ahead of time by prepare_graph(); the graph bakes in the current
+        pf_problem record), the remainder is launched eagerly.  Launches after the device-side stop are
+        no-ops either way."""
         n_iter = int(n_iter)
         if use_graph is None:
             use_graph = os.environ.get("PINNFEM_GRAPH", "1") != "0"
         s = self._stream()
         k = self.GRAPH_ITERS
         if use_graph and n_iter >= k:
-            if getattr(self, "_graph", None) is None:
-                g = C.c_void_p()
-                _capi.check(self.lib.pf_graph_create(self._ref(), k, s, C.byref(g)), "pf_graph_create")
-                self._graph = g
+            self.prepare_graph()
             while n_iter >= k:
                 _capi.check(self.lib.pf_graph_launch(self._graph, s), "pf_graph_launch")
                 n_iter -= k

@@ -73,13 +73,25 @@ def _engine_for(model: FEMModel, measured_disp, measured_dofs) -> HipEngine:
     key = (None if measured_disp is None else np.asarray(measured_disp, dtype=float).tobytes(),
            None if measured_dofs is None else np.asarray(measured_dofs, dtype=int).tobytes(),
            model.nodes.tobytes(), model.elements.tobytes(), model.loads.tobytes(),
-           model.fixed_dofs.tobytes())
+           model.fixed_dofs.tobytes(), _material_signature(model))
     cache = getattr(model, "_pf_engine_cache", None)
     if cache is not None and cache[0] == key and (not cache[1].n_theta or cache[1].theta.still_bound()):
         return cache[1]
     eng = HipEngine(model, measured_disp, measured_dofs, fe_mode=getattr(model, "_pf_fe_mode", None))
     model._pf_engine_cache = (key, eng)
     return eng
+
+
+def _material_signature(model: FEMModel):
+    """What of the material an engine bakes in: which properties are networks (and which module), and the
+    value of every scalar one (the reference re-reads material.*.value() on every assembly)."""
+    sig = []
+    for prop in (model.material.young, model.material.area, model.material.density):
+        if prop.is_trainable():
+            sig.append(("nn", id(prop.net), bool(prop.enforce_positive), float(prop.scale)))
+        else:
+            sig.append(("scalar", float(prop.value())))
+    return tuple(sig)
 
 
 def solve_gd(
@@ -248,7 +260,9 @@ def _solve_gd_sharded(model, config, measured_disp, measured_dofs, lam, u_initia
     from .. import dist as pfd
     key = ("shard", dist.get_rank(), dist.get_world_size(),
            None if measured_disp is None else np.asarray(measured_disp, dtype=float).tobytes(),
-           None if measured_dofs is None else np.asarray(measured_dofs, dtype=int).tobytes())
+           None if measured_dofs is None else np.asarray(measured_dofs, dtype=int).tobytes(),
+           model.nodes.tobytes(), model.elements.tobytes(), model.loads.tobytes(),
+           model.fixed_dofs.tobytes(), _material_signature(model))
     cache = getattr(model, "_pf_shard_cache", None)
     if cache is not None and cache[0] == key and (not cache[1].eng.n_theta or cache[1].eng.theta.still_bound()):
         be = cache[1]

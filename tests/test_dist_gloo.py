@@ -56,3 +56,20 @@ def test_partition_properties():
     # every global node owned exactly once
     owned = np.concatenate([s.nodes_global[~s.ghost_mask[0::2]] for s in shards])
     assert sorted(owned) == list(range(11))
+
+
+def test_broadcast_theta_makes_replicas_identical(tmp_path):
+    """Networks built from an unseeded RNG differ per process; the sharded path replicates theta, so every
+    rank must start from rank 0's values (the CLI under torchrun never reconciled them)."""
+    out = str(tmp_path / "bcast.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3",
+           "--master-addr", "127.0.0.1", "--master-port", "29614",
+           os.path.join(ROOT, "tests", "dist_bcast_worker.py"), out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    with np.load(out) as z:
+        before, after = z["before"], z["after"]
+    assert not np.array_equal(before[0], before[1]) and not np.array_equal(before[0], before[2])
+    for k in range(3):
+        assert np.array_equal(after[k], before[0])     # bit for bit rank 0's vector
