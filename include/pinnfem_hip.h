@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 2
+#define PF_ABI_VERSION 3
 
 /* error codes */
 #define PF_OK 0
@@ -43,7 +43,10 @@ extern "C" {
 /* MLP engines (pf_problem.wg_mode) */
 #define PF_WG_SHUFFLE 0 /* VALU mat-vecs, weight gradients by wave shuffles (slow cross-check) */
 #define PF_WG_MFMA 1    /* VALU mat-vecs, weight gradients on v_mfma_f32_16x16x4_f32 (LDS tiles) */
-#define PF_WG_MFMA44 2  /* everything on v_mfma_f32_4x4x1_16B_f32, one element per lane (default) */
+#define PF_WG_MFMA44 2  /* everything on v_mfma_f32_4x4x1_16B_f32, one element per lane (exact f32 fma chains) */
+#define PF_WG_MFMA32 3  /* v_mfma_f32_32x32x16_f16 with 2-way split operands (f32-grade products on the f16 matrix
+                           cores; default for widths <= PF_N32_WIDTH_MAX) */
+#define PF_N32_WIDTH_MAX 30
 
 /* element-force formulations */
 #define PF_FE_REFERENCE 0 /* 4-term dot per row, the reference's order (nn_assembly.py:96-100) */
@@ -150,6 +153,13 @@ typedef struct pf_problem {
   /* != 0: prop_e and prop_a hold 2*n_elems floats; the iteration graph then alternates between the two
    * halves, so the forwards of iteration t+1 need not wait for the last reader of iteration t's properties */
   int32_t prop_double;
+  /* MFMA32 engine: split-f16 operand image of the enabled nets (pf_net_op_count() floats each, at op_off[k]),
+   * rebuilt from theta by pf_pack_theta and by every theta update; NULL unless wg_mode == PF_WG_MFMA32 */
+  float* net_op;
+  int32_t op_off[2];
+  /* 2^coord_exp * max |centroid coordinate| <= 2^14: scale of the coordinates inside the f16 gradient products */
+  int32_t coord_exp;
+  int32_t _pad2;
 } pf_problem;
 
 #define PF_MAX_BLOCKS 1024
@@ -172,6 +182,8 @@ int pf_net_pad_count(int in_dim, int width, int n_hidden);
 int pf_net_pad_index(int in_dim, int width, int n_hidden, int local);
 /* sizeof of the ABI structs: 0 pf_mesh, 1 pf_net, 2 pf_state, 3 pf_problem (binding self-check) */
 int pf_sizeof(int what);
+/* floats of operand-image workspace (pf_problem.net_op) one net needs with the MFMA32 engine, or <0 */
+int pf_net_op_count(int in_dim, int width, int n_hidden);
 /* floats needed in pf_problem.partials for the given block count */
 long long pf_partials_count(const pf_problem* p);
 

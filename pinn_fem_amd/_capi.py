@@ -11,10 +11,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpinnfem_hip.so")
 
-PF_ABI_VERSION = 2
+PF_ABI_VERSION = 3
 PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_DOF_FIXED, PF_DOF_MEASURED, PF_DOF_SHARED, PF_DOF_GHOST = 1, 2, 4, 8
-PF_WG_SHUFFLE, PF_WG_MFMA, PF_WG_MFMA44 = 0, 1, 2
+PF_WG_SHUFFLE, PF_WG_MFMA, PF_WG_MFMA44, PF_WG_MFMA32 = 0, 1, 2, 3
+PF_N32_WIDTH_MAX = 30
 PF_FE_REFERENCE, PF_FE_DELTA = 0, 1
 PF_HIST_COLS = 6
 PF_MAX_BLOCKS = 1024
@@ -81,6 +82,7 @@ class PfProblem(C.Structure):
         ("shared_dofs", C.c_void_p), ("shared_slot", C.c_void_p),
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
         ("iface_elems", C.c_void_p), ("n_iface_elems", C.c_int32), ("prop_double", C.c_int32),
+        ("net_op", C.c_void_p), ("op_off", C.c_int32 * 2), ("coord_exp", C.c_int32), ("_pad2", C.c_int32),
     ]
 
 
@@ -94,6 +96,7 @@ SYMBOLS = {
     "pf_net_pad_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pf_net_pad_index": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pf_sizeof": (C.c_int, [C.c_int]),
+    "pf_net_op_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pf_partials_count": (C.c_longlong, [_PP]),
     "pf_pack_theta": (C.c_int, [_PP, C.c_void_p]),
     "pf_net_forward": (C.c_int, [_PP, C.c_int, C.c_void_p]),

@@ -22,6 +22,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "lib", "libpinnfem_hip.so")
 STAMP = os.path.join(HERE, "lib", "libpinnfem_hip.stamp")   # hash of everything the library was built from
 WIDTHS = (4, 8, 12, 16, 20, 24, 28, 32)
+NR_BUCKETS = (2, 4, 6, 8, 10, 12, 15)      # pf_net32.hip: registers per lane (widths <= 2*nr)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
          "-I" + CSRC, "-I/opt/rocm/include", "-Wall", "-Wno-unused-function"]
@@ -33,6 +34,8 @@ def _sources():
     # removes the v_accvgpr_read copies in front of every tanh
     units += [(f"pf_net44_{w}.o", "pf_net44.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
               for w in reversed(WIDTHS)]
+    units += [(f"pf_net32_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
+              for r in reversed(NR_BUCKETS)]
     units += [(f"pf_net_{w}.o", "pf_net.hip", [f"-DPF_HP={w}"]) for w in WIDTHS]
     units += [(f"pf_net16_{w}.o", "pf_net16.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]) for w in WIDTHS]
     return units

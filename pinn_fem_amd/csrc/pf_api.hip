@@ -4,6 +4,7 @@
 #include <string.h>
 #include <stdio.h>
 #include "pf_common.h"
+#include "pf_net32.h"
 
 // launchers from pf_mesh.hip
 int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s,
@@ -79,6 +80,11 @@ static int check_problem(const pf_problem* p) {
     if (!p->theta || !p->theta_pad || !p->pad_index || !p->g_ea || !p->grad_theta)
       return fail(PF_ERR_ARG, "null parameter workspace");
     if ((k == 0 && !p->prop_e) || (k == 1 && !p->prop_a)) return fail(PF_ERR_ARG, "null property array");
+    if (p->wg_mode == PF_WG_MFMA32) {
+      if (n.width > PF_N32_WIDTH_MAX)
+        return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine supports widths up to 30 (use PF_WG_MFMA44 beyond)");
+      if (!p->net_op) return fail(PF_ERR_ARG, "MFMA32 engine needs the operand image workspace (net_op)");
+    }
   }
   return PF_OK;
 }
@@ -98,21 +104,37 @@ static int check_problem(const pf_problem* p) {
 
 static int net_forward16(const pf_problem* p, int which, hipStream_t s) { PF_WIDTH_SWITCH(pf_launch_net16_forward_) }
 
+// MFMA32 engine: one translation unit per register bucket
+#define PF_NR_SWITCH(PREFIX)                                      \
+  switch (pf_net32_bucket(p->net[which].width)) {                 \
+    case 2: return PREFIX##2(p, which, s);                        \
+    case 4: return PREFIX##4(p, which, s);                        \
+    case 6: return PREFIX##6(p, which, s);                        \
+    case 8: return PREFIX##8(p, which, s);                        \
+    case 10: return PREFIX##10(p, which, s);                      \
+    case 12: return PREFIX##12(p, which, s);                      \
+    case 15: return PREFIX##15(p, which, s);                      \
+  }                                                               \
+  return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
+
 static int net_forward(const pf_problem* p, int which, hipStream_t s) {
   // PF_FWD_F16=1: the split-f16 forward kernel (pf_net16.hip) in place of the 4x4x1 f32 one
   static const bool fwd16 = getenv("PF_FWD_F16") && atoi(getenv("PF_FWD_F16")) != 0;
+  if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_forward_) }
   if (p->wg_mode == PF_WG_MFMA44 && fwd16) return net_forward16(p, which, s);
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_forward_) }
   PF_WIDTH_SWITCH(pf_launch_net_forward_)
 }
 
 static int net_backward(const pf_problem* p, int which, hipStream_t s) {
+  if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_backward_) }
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_backward_) }
   PF_WIDTH_SWITCH(pf_launch_net_backward_)
 }
 
 // backward that also computes and stores the element adjoint g_ea (MFMA44 engine only)
 static int net_backward_gea(const pf_problem* p, int which, hipStream_t s) {
+  if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_backward_gea_) }
   PF_WIDTH_SWITCH(pf_launch_net44_backward_gea_)
 }
 
@@ -175,6 +197,12 @@ int pf_net_pad_index(int in_dim, int width, int n_hidden, int local) {
   q -= width;
   if (q == 0) return pf_pad_wo(hp, n_hidden) + hp;
   return PF_ERR_ARG;
+}
+
+int pf_net_op_count(int in_dim, int width, int n_hidden) {
+  if (width < 1 || width > PF_N32_WIDTH_MAX || n_hidden < 1 || n_hidden > 3 || (in_dim != 2 && in_dim != 3))
+    return PF_ERR_UNSUPPORTED;
+  return (pf_n32_bytes(n_hidden) + 3) / 4;
 }
 
 long long pf_partials_count(const pf_problem* p) {
@@ -278,7 +306,7 @@ static int enqueue_iteration(const pf_problem* p, int fuse_adam, int finalize_mo
   if (p->net[1].enabled) PF_TRY(net_forward(p, 1, s), "net_forward");
   PF_MARK(K_RESIDUAL);
   PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
-  const bool fuse_gea = any_net && p->wg_mode == PF_WG_MFMA44;
+  const bool fuse_gea = any_net && (p->wg_mode == PF_WG_MFMA44 || p->wg_mode == PF_WG_MFMA32);
   const int first = p->net[0].enabled ? 0 : 1;
   PF_MARK(K_ADJOINT);
   if (any_net && !fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
@@ -359,7 +387,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     }
     return PF_OK;
   }
-  const bool fuse_gea = p->wg_mode == PF_WG_MFMA44;
+  const bool fuse_gea = (p->wg_mode == PF_WG_MFMA44 || p->wg_mode == PF_WG_MFMA32);
   const int first = p->net[0].enabled ? 0 : 1;
   // The runtime keeps the FIRST-created child of a node on its parent's hardware queue and moves later
   // children to other queues; a dependency whose last parent sits on another queue costs ~10 us (kernel trace).
@@ -636,7 +664,7 @@ int pf_shard_backward(const pf_problem* p, const float* iface1, float* buf2, voi
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
   PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, iface1), "node_residual");
   if (any_net) {
-    const bool fuse_gea = p->wg_mode == PF_WG_MFMA44;
+    const bool fuse_gea = p->wg_mode == PF_WG_MFMA44 || p->wg_mode == PF_WG_MFMA32;
     const int first = p->net[0].enabled ? 0 : 1;
     if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
     for (int k = 0; k < 2; ++k)
@@ -725,7 +753,7 @@ int pf_shard_graph_create(const pf_problem* p, float* buf1, float* buf2, int wit
   hipStream_t fin = side[0], gu = side[1];
   rc = capture_graph(s, [&]() -> int {
     const bool any_net = p->net[0].enabled || p->net[1].enabled;
-    const bool fuse_gea = any_net && p->wg_mode == PF_WG_MFMA44;
+    const bool fuse_gea = any_net && (p->wg_mode == PF_WG_MFMA44 || p->wg_mode == PF_WG_MFMA32);
     const int first = p->net[0].enabled ? 0 : 1;
     // branch `fin`: bookkeeping of the previous iteration from the reduced sums (buf1[2], tail of buf2)
     if (with_finalize) {

@@ -209,7 +209,18 @@ inline int pf_net44_threads(const pf_problem* p) {
   }
   return waves * 64;
 }
+// MFMA32 engine: 8-wave blocks, one per CU (two waves per SIMD), every wave walks 64-element tasks
+#define PF_NET32_THREADS 512
+inline int pf_net32_blocks(const pf_problem* p) {
+  static const int cap = getenv("PF_NET32_BLOCKS") ? atoi(getenv("PF_NET32_BLOCKS")) : 256;
+  int nb = (p->mesh.n_elems + PF_NET32_THREADS - 1) / PF_NET32_THREADS;
+  if (nb > cap) nb = cap;
+  if (nb > p->n_part_blocks) nb = p->n_part_blocks;
+  if (nb < 1) nb = 1;
+  return nb;
+}
 inline int pf_net_blocks(const pf_problem* p) {
+  if (p->wg_mode == PF_WG_MFMA32) return pf_net32_blocks(p);
   const bool m44 = p->wg_mode == PF_WG_MFMA44;
   const int threads = m44 ? pf_net44_threads(p) : PF_NET_THREADS;
   int cap = m44 ? p->n_part_blocks * PF_NET_THREADS / threads : p->n_part_blocks;   // same number of waves
@@ -239,6 +250,25 @@ PF_DECL_NET_LAUNCHERS(20)
 PF_DECL_NET_LAUNCHERS(24)
 PF_DECL_NET_LAUNCHERS(28)
 PF_DECL_NET_LAUNCHERS(32)
+
+// launchers of pf_net32.hip, one translation unit per register bucket (-DPF_NR=<nr>): nets of width <= 2*nr
+#define PF_DECL_NET32_LAUNCHERS(NRB)                                                       \
+  int pf_launch_net32_forward_##NRB(const pf_problem* p, int which, hipStream_t s);       \
+  int pf_launch_net32_backward_##NRB(const pf_problem* p, int which, hipStream_t s);      \
+  int pf_launch_net32_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s);
+PF_DECL_NET32_LAUNCHERS(2)
+PF_DECL_NET32_LAUNCHERS(4)
+PF_DECL_NET32_LAUNCHERS(6)
+PF_DECL_NET32_LAUNCHERS(8)
+PF_DECL_NET32_LAUNCHERS(10)
+PF_DECL_NET32_LAUNCHERS(12)
+PF_DECL_NET32_LAUNCHERS(15)
+// register bucket of a net width (1..30), or -1
+inline int pf_net32_bucket(int width) {
+  const int nr = (width + 1) / 2;
+  if (width < 1 || width > PF_N32_WIDTH_MAX) return -1;
+  return nr <= 2 ? 2 : nr <= 4 ? 4 : nr <= 6 ? 6 : nr <= 8 ? 8 : nr <= 10 ? 10 : nr <= 12 ? 12 : 15;
+}
 
 void pf_set_error(const char* msg);
 

@@ -15,6 +15,7 @@
 // atomics and is bitwise reproducible.  K is never formed: K u and K^T g are applied matrix-free.
 #include <stdlib.h>
 #include "pf_common.h"
+#include "pf_net32.h"
 
 // torch.optim.Adam is a sequence of separately rounded tensor ops (lerp_, mul_, addcmul_, sqrt, div, add,
 // addcdiv_); with the default -ffp-contract=fast hipcc fuses some of them into fma, and not the same ones in
@@ -228,14 +229,32 @@ __device__ __forceinline__ void theta_stage2(const pf_problem& P, int fuse_adam,
   }
 }
 
-__global__ __launch_bounds__(1024) void k_theta_stage2(pf_problem P, int fuse_adam) {
-  if (P.state->done) return;
-  theta_stage2(P, fuse_adam, nullptr);
+// MFMA32 engine: rebuild the split-f16 operand images of the enabled nets from `th` (the flat active
+// parameters: LDS copy of the values just written, or global theta).  Every thread of the block; has barriers.
+__device__ __forceinline__ void pack_net_ops(const pf_problem& P, const float* th, float* scratch64) {
+  if (P.wg_mode != PF_WG_MFMA32 || !P.net_op) return;
+  for (int k = 0; k < 2; ++k) {
+    if (!P.net[k].enabled) continue;
+    pf_n32_pack(P.net[k], th + P.net[k].theta_off, reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]), scratch64);
+  }
 }
 
-__global__ void k_pack_theta(pf_problem P) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < P.n_theta_active) P.theta_pad[P.pad_index[q]] = P.theta[q];
+__global__ __launch_bounds__(1024) void k_theta_stage2(pf_problem P, int fuse_adam) {
+  if (P.state->done) return;
+  extern __shared__ float new_theta[];   // n_theta_active floats (MFMA32 engine only)
+  __shared__ float scratch[64];
+  const bool ops = P.wg_mode == PF_WG_MFMA32 && fuse_adam;
+  theta_stage2(P, fuse_adam, ops ? new_theta : nullptr);
+  if (ops) {
+    __syncthreads();
+    pack_net_ops(P, new_theta, scratch);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pack_theta(pf_problem P) {
+  __shared__ float scratch[64];
+  for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) P.theta_pad[P.pad_index[q]] = P.theta[q];
+  pack_net_ops(P, P.theta, scratch);
 }
 
 // ---- parameter update + monitors / history / stop test / next Adam scalars ------------------------
@@ -251,7 +270,14 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
   extern __shared__ float new_theta[];  // n_theta_active floats
   __shared__ double dred[16];
   __shared__ float wnorm[16];
-  if (with_theta) theta_stage2(P, mode == 0, new_theta);
+  __shared__ float scratch[64];
+  if (with_theta) {
+    theta_stage2(P, mode == 0, new_theta);
+    if (mode == 0) {
+      __syncthreads();
+      pack_net_ops(P, new_theta, scratch);
+    }
+  }
   double a = 0.0, b = 0.0, c = 0.0;
   for (int i = threadIdx.x; i < nb_node; i += blockDim.x) {
     a += (double)P.partials[PF_PART_R2 + i];
@@ -479,6 +505,9 @@ __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node
   PF_NO_CONTRACT
   if (P.state->done) return;   // sums3 keeps the previous (final) value: finalize ignores it once done
   __shared__ double dred[16];
+  __shared__ float scratch[64];
+  extern __shared__ float new_theta_dyn[];     // n_theta_active floats with the MFMA32 engine, else none
+  float* new_theta = P.wg_mode == PF_WG_MFMA32 ? new_theta_dyn : nullptr;
   const pf_mesh& M = P.mesh;
   const float bc2s = P.state->bc2_sqrt;
   const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
@@ -497,7 +526,12 @@ __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node
       P.v_t[q] = v;
       P.theta[q] = th;
       P.theta_pad[P.pad_index[q]] = th;
+      if (new_theta) new_theta[q] = th;
     }
+  }
+  if (new_theta) {
+    __syncthreads();
+    pack_net_ops(P, new_theta, scratch);
   }
   double c = 0.0;
   {
@@ -577,6 +611,9 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_adam_u(pf_problem P) {
 __global__ __launch_bounds__(1024) void k_adam_theta(pf_problem P) {
   PF_NO_CONTRACT
   if (P.state->done) return;
+  __shared__ float scratch[64];
+  extern __shared__ float new_theta_dyn[];
+  float* new_theta = P.wg_mode == PF_WG_MFMA32 ? new_theta_dyn : nullptr;
   const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
   const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
   const float eps = (float)P.eps;
@@ -592,6 +629,11 @@ __global__ __launch_bounds__(1024) void k_adam_theta(pf_problem P) {
     P.v_t[q] = v;
     P.theta[q] = th;
     P.theta_pad[P.pad_index[q]] = th;
+    if (new_theta) new_theta[q] = th;
+  }
+  if (new_theta) {
+    __syncthreads();
+    pack_net_ops(P, new_theta, scratch);
   }
 }
 
@@ -735,7 +777,9 @@ int pf_launch_theta_stage1(const pf_problem* p, hipStream_t s) {
 
 int pf_launch_theta_stage2(const pf_problem* p, int fuse_adam, hipStream_t s) {
   if (p->n_theta_active <= 0) return PF_OK;
-  hipLaunchKernelGGL(k_theta_stage2, dim3(1), dim3(1024), 0, s, *p, fuse_adam);
+  const size_t lds = p->wg_mode == PF_WG_MFMA32 ? (size_t)p->n_theta_active * sizeof(float) : 0;
+  if (lds > 60000) { pf_set_error("too many trainable parameters for the fused theta update"); return PF_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL(k_theta_stage2, dim3(1), dim3(1024), lds, s, *p, fuse_adam);
   return PF_CHECK_LAUNCH();
 }
 
@@ -748,8 +792,7 @@ int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s) {
 
 int pf_launch_pack_theta(const pf_problem* p, hipStream_t s) {
   if (p->n_theta_active <= 0) return PF_OK;
-  const int nb = (p->n_theta_active + 255) / 256;
-  hipLaunchKernelGGL(k_pack_theta, dim3(nb), dim3(256), 0, s, *p);
+  hipLaunchKernelGGL(k_pack_theta, dim3(1), dim3(256), 0, s, *p);
   return PF_CHECK_LAUNCH();
 }
 
@@ -827,7 +870,8 @@ int pf_launch_shard_pack(const pf_problem* p, float* buf2, hipStream_t s) {
 }
 int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* sums3, hipStream_t s) {
   const int nb = pf_node_blocks(p->mesh.n_nodes);
-  hipLaunchKernelGGL(k_shard_update, dim3(1), dim3(1024), 0, s, *p, nb, buf2, sums3);
+  const size_t lds = p->wg_mode == PF_WG_MFMA32 ? (size_t)p->n_theta_active * sizeof(float) : 0;
+  hipLaunchKernelGGL(k_shard_update, dim3(1), dim3(1024), lds, s, *p, nb, buf2, sums3);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_local_sums(const pf_problem* p, float* sums3, hipStream_t s) {
@@ -842,7 +886,8 @@ int pf_launch_adam_u(const pf_problem* p, hipStream_t s) {
 }
 int pf_launch_adam_theta(const pf_problem* p, hipStream_t s) {
   if (p->n_theta_active <= 0) return PF_OK;
-  hipLaunchKernelGGL(k_adam_theta, dim3(1), dim3(1024), 0, s, *p);
+  const size_t lds = p->wg_mode == PF_WG_MFMA32 ? (size_t)p->n_theta_active * sizeof(float) : 0;
+  hipLaunchKernelGGL(k_adam_theta, dim3(1), dim3(1024), lds, s, *p);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, hipStream_t s) {

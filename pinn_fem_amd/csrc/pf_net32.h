@@ -1,0 +1,113 @@
+// pf_net32.h — layout of the split-f16 operand image of one MLP (MFMA32 engine, pf_net32.hip) and the
+// device routine that builds it from the torch-order parameters.  Shared by pf_net32.hip (consumer) and
+// pf_mesh.hip (producer: pf_pack_theta and the theta update of every iteration).
+//
+// Unit u of a layer lives in accumulator register r = u>>1 of the lanes of half-wave h = u&1 of a
+// v_mfma_f32_32x32x16_f16 result tile, i.e. in tile row rho(u) = (r&3) + 8*(r>>2) + 4*h, the ELEMENT on the
+// tile column (= lane&31).  A lane's result registers 8s..8s+7 are then, converted to f16, exactly its eight
+// k-slots of k-step s of the next product (slot j of half h carries unit 2*(8s+j)+h): activations never leave
+// their lane between layers, and only the weight operand has to agree with that order — which is what the
+// image below encodes.  Units >= width are structural zeros.
+#pragma once
+#include "pf_common.h"
+
+#define PF_N32_MAX_WIDTH 30        /* units 30, 31 (register 15) are reserved: bias column of the gradient tiles */
+#define PF_N32_KA 2048.0f          /* activations are carried as KA * tanh: lo = a' - f16(a') stays a normal f16 */
+#define PF_N32_KW 16.0f            /* forward weights as KW * w, backward (transposed) as KB * w */
+#define PF_N32_KB 16.0f
+#define PF_N32_KL 256.0f           /* load factor in the gradient tile */
+
+// byte offsets inside one net's image (all multiples of 16)
+__host__ __device__ constexpr int pf_n32_off_w1() { return 16; }                       // [16 r][2 h] float4: w1[u][0..in-1], b1[u]
+__host__ __device__ constexpr int pf_n32_off_wo() { return 16 + 512; }                 // [2 h][16 r] float: wo[2r+h]
+__host__ __device__ constexpr int pf_n32_off_bo() { return 16 + 512 + 128; }           // float bo (+pad)
+__host__ __device__ constexpr int pf_n32_off_layers() { return 16 + 512 + 128 + 16; }
+// per hidden layer l = 2..L: bias C-vector [2 h][16 r] float (KA*KW*b), forward operand, backward operand
+#define PF_N32_LAYER_BYTES (128 + 4096 + 4096)
+__host__ __device__ constexpr int pf_n32_off_bias(int l) { return pf_n32_off_layers() + (l - 2) * PF_N32_LAYER_BYTES; }
+__host__ __device__ constexpr int pf_n32_off_af(int l) { return pf_n32_off_bias(l) + 128; }   // [2 split][2 ks][64 lane][8] f16
+__host__ __device__ constexpr int pf_n32_off_ab(int l) { return pf_n32_off_af(l) + 4096; }
+__host__ __device__ constexpr int pf_n32_bytes(int n_hidden) { return pf_n32_off_layers() + (n_hidden - 1) * PF_N32_LAYER_BYTES; }
+// header: float[0] = bound on max_l 4^(L-l) |d_l| / |g_z| (the backward's power-of-two scaling), float[1..3] spare
+
+// Build the image of net `which` from its parameters `th` (torch parameters() order: W1 [w][in], b1, (Wl [w][w],
+// bl)*, Wo [1][w], bo).  Called by every thread of one block; `scratch` = 64 floats of LDS.  Contains barriers.
+__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, float* scratch) {
+  const int W = net.width, L = net.n_hidden, IN = net.in_dim;
+  const int o_b1 = W * IN, o_h = W * IN + W, per = W * W + W, o_wo = o_h + (L - 1) * per, o_bo = o_wo + W;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  // layer 1 rows and the output row (float)
+  float4* w1 = reinterpret_cast<float4*>(img + pf_n32_off_w1());
+  for (int i = tid; i < 32; i += nt) {
+    const int r = i >> 1, h = i & 1, u = 2 * r + h;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u < W) {
+      v.x = th[u * IN + 0];
+      v.y = th[u * IN + 1];
+      if (IN == 3) { v.z = th[u * IN + 2]; v.w = th[o_b1 + u]; }
+      else { v.z = th[o_b1 + u]; }
+    }
+    w1[i] = v;
+    const int hh = i >> 4, rr = i & 15, uu = 2 * rr + hh;
+    reinterpret_cast<float*>(img + pf_n32_off_wo())[i] = uu < W ? th[o_wo + uu] : 0.f;
+  }
+  if (tid == 0) reinterpret_cast<float*>(img + pf_n32_off_bo())[0] = th[o_bo];
+  for (int l = 2; l <= L; ++l) {
+    const float* Wl = th + o_h + (l - 2) * per;
+    const float* bl = Wl + W * W;
+    float* bias = reinterpret_cast<float*>(img + pf_n32_off_bias(l));
+    for (int i = tid; i < 32; i += nt) {
+      const int hh = i >> 4, rr = i & 15, uu = 2 * rr + hh;
+      bias[i] = uu < W ? (PF_N32_KA * PF_N32_KW) * bl[uu] : 0.f;
+    }
+    _Float16* af = reinterpret_cast<_Float16*>(img + pf_n32_off_af(l));
+    _Float16* ab = reinterpret_cast<_Float16*>(img + pf_n32_off_ab(l));
+    for (int i = tid; i < 2 * 2 * 64 * 8; i += nt) {
+      const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) & 1, sp = i >> 10;
+      const int rho = lane & 31, hh = lane >> 5;
+      const int u_row = 2 * ((rho & 3) + 4 * (rho >> 3)) + ((rho >> 2) & 1);   // unit on tile row rho
+      const int u_k = 2 * (8 * ks + j) + hh;                                     // unit in k-slot j of half hh
+      float vf = 0.f, vb = 0.f;
+      if (u_row < W && u_k < W) {
+        vf = PF_N32_KW * Wl[u_row * W + u_k];     // z_l[u_row]   += W_l[u_row][u_k] a_{l-1}[u_k]
+        vb = PF_N32_KB * Wl[u_k * W + u_row];     // dh_{l-1}[u_row] += W_l[u_k][u_row] d_l[u_k]
+      }
+      const _Float16 fh = (_Float16)vf, bh = (_Float16)vb;
+      af[i] = sp ? (_Float16)(vf - (float)fh) : fh;
+      ab[i] = sp ? (_Float16)(vb - (float)bh) : bh;
+    }
+  }
+  // bound for the backward scaling: v_L[j] = |wo[j]|, v_{l-1}[k] = sum_j |W_l[j][k]| v_l[j];
+  // bound = max_l 4^(L-l) max_k v_l[k]  (|d_l| <= |g_z| v_l since 4 t = 1 - a^2 <= 1)
+  float* va = scratch;
+  float* vb2 = scratch + 32;
+  if (tid < 32) va[tid] = tid < W ? fabsf(th[o_wo + tid]) : 0.f;
+  __syncthreads();
+  float bound = 0.f;   // (thread 0's copy is the one stored)
+  float grow = 1.f;
+  for (int l = L; l >= 1; --l) {
+    if (tid == 0) {
+      float m = 0.f;
+      for (int k = 0; k < W; ++k) m = fmaxf(m, va[k]);
+      bound = fmaxf(bound, grow * m);
+    }
+    grow *= 4.f;
+    if (l >= 2) {
+      const float* Wl = th + o_h + (l - 2) * per;
+      if (tid < 32) {
+        float a = 0.f;
+        if (tid < W)
+          for (int j = 0; j < W; ++j) a += fabsf(Wl[j * W + tid]) * va[j];
+        vb2[tid] = a;
+      }
+      __syncthreads();
+      float* t = va; va = vb2; vb2 = t;
+    }
+  }
+  if (tid == 0) {
+    float* hdr = reinterpret_cast<float*>(img);
+    hdr[0] = bound > 0.f ? bound : 1.f;
+    hdr[1] = hdr[2] = hdr[3] = 0.f;
+  }
+  __syncthreads();
+}

@@ -116,8 +116,23 @@ class HipEngine:
         self.pad_index = torch.tensor(pad_index if pad_index else [0], dtype=torch.int32, device=dev)
 
         if wg_mode is None:
-            wg_mode = int(os.environ.get("PINNFEM_WG_MODE", _capi.PF_WG_MFMA44))
+            wg_mode = int(os.environ.get("PINNFEM_WG_MODE", _capi.PF_WG_MFMA32))
+        if wg_mode == _capi.PF_WG_MFMA32 and any(sp.enabled and sp.width > _capi.PF_N32_WIDTH_MAX for sp in self.specs):
+            wg_mode = _capi.PF_WG_MFMA44          # widths 31, 32: the exact-f32 4x4x1 engine (another HIP engine)
         self.wg_mode = wg_mode
+        # MFMA32 engine: operand images of the enabled nets; scale of the coordinates in the f16 gradient products
+        op_off, self._op_off = 0, [0, 0]
+        if wg_mode == _capi.PF_WG_MFMA32:
+            for k, spec in enumerate(self.specs):
+                if spec.enabled:
+                    cnt = lib.pf_net_op_count(spec.in_dim, spec.width, spec.n_hidden)
+                    _capi.check(min(cnt, 0), "pf_net_op_count")
+                    self._op_off[k] = op_off
+                    op_off += (cnt + 63) // 64 * 64
+        self.net_op = torch.zeros(max(op_off, 1), dtype=torch.float32, device=dev)
+        cmax = float(np.max(np.abs(hp.ecent))) if hp.n_elems else 1.0
+        self.coord_exp = 14 - int(np.ceil(np.log2(max(cmax, 1e-30)))) if cmax > 0 else 0
+        self.coord_exp = int(min(max(self.coord_exp, -100), 100))
         if fe_mode is None:
             fe_mode = int(os.environ.get("PINNFEM_FE_MODE", _capi.PF_FE_REFERENCE))
         self.fe_mode = fe_mode
@@ -218,6 +233,9 @@ class HipEngine:
         P.iface_elems = self.iface_elems.data_ptr() if self.n_iface_elems else None
         P.n_iface_elems = self.n_iface_elems
         P.prop_double = 1
+        P.net_op = self.net_op.data_ptr() if self.wg_mode == _capi.PF_WG_MFMA32 else None
+        P.op_off[0], P.op_off[1] = self._op_off
+        P.coord_exp = self.coord_exp
         self._configured = True
 
     def _ref(self):

@@ -15,7 +15,7 @@ from helpers import (example_problem, load_npz, load_run, mesh_problem, orc, pro
 
 pytestmark = pytest.mark.gpu
 
-WG_MODES = [2, 1, 0]  # PF_WG_MFMA44 (default), PF_WG_MFMA, PF_WG_SHUFFLE
+WG_MODES = [3, 2, 1, 0]  # PF_WG_MFMA32 (default), PF_WG_MFMA44, PF_WG_MFMA, PF_WG_SHUFFLE
 
 
 def _engine(model, mv, md, wg, fe=0):
@@ -408,7 +408,7 @@ def test_api_pinn_gd_identifies_stiffness(tmp_path):
     assert len(out["convergence_history"]) == 150
 
 
-@pytest.mark.parametrize("wg", [2, 1])
+@pytest.mark.parametrize("wg", [3, 2, 1])
 @pytest.mark.parametrize("width,layers,dim", [(1, 1, 2), (4, 1, 2), (7, 2, 2), (8, 3, 2), (12, 2, 1), (16, 2, 2),
                                                 (20, 3, 2), (24, 2, 2), (28, 1, 1), (32, 2, 2), (32, 3, 1), (15, 2, 2)])
 def test_net_shape_menu(width, layers, dim, wg):
