@@ -160,6 +160,10 @@ typedef struct pf_problem {
   /* 2^coord_exp * max |centroid coordinate| <= 2^14: scale of the coordinates inside the f16 gradient products */
   int32_t coord_exp;
   int32_t _pad2;
+  /* element stiffness s = (E*A)/l0 [n_elems] (2*n_elems with prop_double), written by the MFMA32 forward pass
+   * of the LAST evaluated net (same float operations as nn_assembly.py:74) and read by the node kernels instead of
+   * E, A and l0; NULL: the node kernels compute it from prop_e / prop_a / the constant properties */
+  float* elem_s;
 } pf_problem;
 
 #define PF_MAX_BLOCKS 1024

@@ -83,6 +83,7 @@ class PfProblem(C.Structure):
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
         ("iface_elems", C.c_void_p), ("n_iface_elems", C.c_int32), ("prop_double", C.c_int32),
         ("net_op", C.c_void_p), ("op_off", C.c_int32 * 2), ("coord_exp", C.c_int32), ("_pad2", C.c_int32),
+        ("elem_s", C.c_void_p),
     ]
 
 

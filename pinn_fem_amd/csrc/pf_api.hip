@@ -117,7 +117,15 @@ static int net_forward16(const pf_problem* p, int which, hipStream_t s) { PF_WID
   }                                                               \
   return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
 
-static int net_forward(const pf_problem* p, int which, hipStream_t s) {
+static int net_forward_impl(const pf_problem* p, int which, hipStream_t s);
+// write_s == 0: this forward is followed by the other net's, which writes the element stiffness (pf_problem.elem_s)
+static int net_forward(const pf_problem* p, int which, hipStream_t s, int write_s = 1) {
+  if (write_s || !p->elem_s) return net_forward_impl(p, which, s);
+  pf_problem q = *p;
+  q.elem_s = nullptr;
+  return net_forward_impl(&q, which, s);
+}
+static int net_forward_impl(const pf_problem* p, int which, hipStream_t s) {
   // PF_FWD_F16=1: the split-f16 forward kernel (pf_net16.hip) in place of the 4x4x1 f32 one
   static const bool fwd16 = getenv("PF_FWD_F16") && atoi(getenv("PF_FWD_F16")) != 0;
   if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_forward_) }
@@ -301,7 +309,7 @@ static int enqueue_iteration(const pf_problem* p, int fuse_adam, int finalize_mo
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
 #define PF_MARK(k) do { if (ev && hipEventRecord(ev[k], s) != hipSuccess) return fail(PF_ERR_HIP, "hipEventRecord failed"); } while (0)
   PF_MARK(K_FWD_E);
-  if (p->net[0].enabled) PF_TRY(net_forward(p, 0, s), "net_forward");
+  if (p->net[0].enabled) PF_TRY(net_forward(p, 0, s, !p->net[1].enabled), "net_forward");
   PF_MARK(K_FWD_A);
   if (p->net[1].enabled) PF_TRY(net_forward(p, 1, s), "net_forward");
   PF_MARK(K_RESIDUAL);
@@ -417,22 +425,13 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     if (pingpong && (i & 1)) {
       q.prop_e += q.mesh.n_elems;
       q.prop_a += q.mesh.n_elems;
+      if (q.elem_s) q.elem_s += q.mesh.n_elems;
     }
     if (i > 0 && !pingpong && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    // the two forwards are independent, but running the second on branch A beside the first measured
-    // SLOWER (0.195 vs 0.190 ms per iteration): both are bound by the same f32 pipe.  PF_FWD_PARALLEL=1 keeps
-    // the experiment reachable.
-    static const bool fwd_par = getenv("PF_FWD_PARALLEL") && atoi(getenv("PF_FWD_PARALLEL")) != 0;
-    const bool two = p->net[0].enabled && p->net[1].enabled && fwd_par;
-    if (two) {
-      if (cap_edge(e[4], s, c.a) != PF_OK) return PF_ERR_HIP;
-      PF_TRY(net_forward(p, 0, s), "net_forward");
-      PF_TRY(net_forward(p, 1, c.a), "net_forward");
-      if (cap_edge(e[5], c.a, s) != PF_OK) return PF_ERR_HIP;
-    } else {
-      for (int k = 0; k < 2; ++k)
-        if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
-    }
+    // (the two forwards run one after the other: side by side on two branches they measured slower, 0.195 vs
+    // 0.190 ms per iteration with the f32 engine — the same issue pipe — and the second one writes elem_s from both)
+    for (int k = 0; k < 2; ++k)
+      if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
     if (i > 0 && late_fin) {
       int rc = capture_finalize(i - 1);
       if (rc != PF_OK) return rc;
@@ -650,7 +649,7 @@ int pf_shard_forward(const pf_problem* p, void* stream) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   for (int k = 0; k < 2; ++k)
-    if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+    if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
   return PF_OK;
 }
 
@@ -762,7 +761,7 @@ int pf_shard_graph_create(const pf_problem* p, float* buf1, float* buf2, int wit
       if (hipEventRecord(ev[1], fin) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
     }
     for (int k = 0; k < 2; ++k)
-      if (p->net[k].enabled) PF_TRY(net_forward(p, k, s), "net_forward");
+      if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
     PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, iface1), "node_residual");
     if (any_net && !fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
     bool forked = false;

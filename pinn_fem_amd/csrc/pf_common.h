@@ -110,6 +110,7 @@ __device__ __forceinline__ ElemGeo load_geo(const float* __restrict__ egeo, int 
 }
 
 __device__ __forceinline__ float elem_stiffness(const pf_problem& P, int e, float l0) {
+  if (P.elem_s) return P.elem_s[e];     // written by the forward pass: the same (E * A) / l0
   const float E = P.net[0].enabled ? P.prop_e[e] : P.net[0].scale;
   const float A = P.net[1].enabled ? P.prop_a[e] : P.net[1].scale;
   return (E * A) / l0;  // nn_assembly.py:74 (2-D), :37 (1-D)
@@ -209,11 +210,11 @@ inline int pf_net44_threads(const pf_problem* p) {
   }
   return waves * 64;
 }
-// MFMA32 engine: 8-wave blocks, one per CU (two waves per SIMD), every wave walks 64-element tasks
-#define PF_NET32_THREADS 512
+// MFMA32 engine, backward: one block of 8 or 12 waves per CU (pf_net32.hip decides per kernel), every wave walks
+// 64-element tasks.  Both backward launches of a problem use the same number of blocks (= partial gradient rows).
 inline int pf_net32_blocks(const pf_problem* p) {
   static const int cap = getenv("PF_NET32_BLOCKS") ? atoi(getenv("PF_NET32_BLOCKS")) : 256;
-  int nb = (p->mesh.n_elems + PF_NET32_THREADS - 1) / PF_NET32_THREADS;
+  int nb = (p->mesh.n_elems + 511) / 512;
   if (nb > cap) nb = cap;
   if (nb > p->n_part_blocks) nb = p->n_part_blocks;
   if (nb < 1) nb = 1;

@@ -64,12 +64,15 @@ __device__ __forceinline__ h8 as_h8(unsigned a, unsigned b, unsigned c, unsigned
   return __builtin_bit_cast(h8, u32x4{a, b, c, d});
 }
 
-// two values -> packed hi and lo f16 pairs
+// two values -> packed hi and lo f16 pairs: hi = rtz(a), lo = f16(a - hi) by one mixed-precision fma each
+// (v_fma_mixlo/hi_f16 take the f32 value and the f16 half of `hi` directly: 3 instructions per pair against 8
+// for convert-back, subtract, convert; checked by tools/mix_probe.hip)
 __device__ __forceinline__ void split_pair(float a0, float a1, unsigned& hi, unsigned& lo) {
-  const h2 H = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a0, a1));
-  const h2 Lo = h2{(_Float16)(a0 - (float)H[0]), (_Float16)(a1 - (float)H[1])};
-  hi = __builtin_bit_cast(unsigned, H);
-  lo = __builtin_bit_cast(unsigned, Lo);
+  hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+  unsigned l;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "v"(hi));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "v"(hi));
+  lo = l;
 }
 
 // acc += (Ahi + Alo)(Bhi + Blo) without the lo*lo term; small terms first
@@ -103,11 +106,22 @@ __device__ __forceinline__ float own_total(float p0, float p1) {
   return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 
-// wave maximum of a non-negative value, uniform result
+// wave maximum of a non-negative value, uniform result; DPP row shifts and broadcasts (no LDS round trips):
+// after the four row_shr steps lane 15 of every row holds the row maximum, row_bcast15 / row_bcast31 carry it on,
+// lane 63 ends with the maximum of the wave (invalid source lanes read 0 = the identity for non-negative values)
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+  int x = __builtin_bit_cast(int, v);
+#define PF_DPP_MAX(CTRL, ROWS)                                                                       \
+  x = __builtin_bit_cast(int, fmaxf(__builtin_bit_cast(float, x),                                    \
+                                    __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, CTRL, ROWS, 0xf, false))))
+  PF_DPP_MAX(0x111, 0xf);   // row_shr:1
+  PF_DPP_MAX(0x112, 0xf);   // row_shr:2
+  PF_DPP_MAX(0x114, 0xf);   // row_shr:4
+  PF_DPP_MAX(0x118, 0xf);   // row_shr:8
+  PF_DPP_MAX(0x142, 0xa);   // row_bcast15 -> rows 1, 3
+  PF_DPP_MAX(0x143, 0xc);   // row_bcast31 -> rows 2, 3
+#undef PF_DPP_MAX
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 63));
 }
 
 // ---- activations of one tile kept for the backward pass -------------------------------------------------
@@ -118,16 +132,180 @@ struct TileAct {
   float aL[NR];                      // a'_L in float (output unit and its gradient)
 };
 
-// tanh of the NR pre-activations z[r] * cz; writes the packed pairs (and t, aL) of layer LL
+// Scheduling fence.  Left alone, hipcc serialises each unit's exp -> add -> rcp -> fma chain (the transcendental
+// results are needed a few cycles after issue, so the wave stalls on every step); the stages below issue one kind
+// of instruction for all units of both tiles back to back, which hides those latencies inside the wave.
+#define PF_STAGE() __builtin_amdgcn_sched_barrier(0)
+
+// tanh of the NR pre-activations z[r] * cz of BOTH tiles; writes the packed pairs (and t, aL) of layer LL
 template <int L, bool BWD, int LL>
-__device__ __forceinline__ void activate(TileAct<L, BWD>& A, const float (&z)[NR], float cz) {
+__device__ __forceinline__ void activate2(TileAct<L, BWD>& A0, TileAct<L, BWD>& A1, const float (&z0)[NR],
+                                          const float (&z1)[NR], float cz, int dbg = 0) {
+  float e0[NR], e1[NR];
+  PF_STAGE();
+  if (dbg & 4) {   // timing experiment: no transcendentals
+    sfor<0, NR>([&](auto r) { constexpr int R = r; e0[R] = z0[R] * cz; e1[R] = z1[R] * cz; });
+  } else {
+  sfor<0, NR>([&](auto r) {
+    constexpr int R = r;
+    e0[R] = __builtin_amdgcn_exp2f(z0[R] * cz);
+    e1[R] = __builtin_amdgcn_exp2f(z1[R] * cz);
+  });
+  PF_STAGE();
+  sfor<0, NR>([&](auto r) {
+    constexpr int R = r;
+    e0[R] = __builtin_amdgcn_rcpf(e0[R] + 1.0f);
+    e1[R] = __builtin_amdgcn_rcpf(e1[R] + 1.0f);
+  });
+  }
+  PF_STAGE();
+  float a0[2 * NPR], a1[2 * NPR];
+  sfor<0, NR>([&](auto r) {
+    constexpr int R = r;
+    a0[R] = fmaf(-2.0f * PF_N32_KA, e0[R], PF_N32_KA);
+    a1[R] = fmaf(-2.0f * PF_N32_KA, e1[R], PF_N32_KA);
+    if constexpr (BWD) {
+      A0.t[LL - 1][R] = fmaf(-e0[R], e0[R], e0[R]);
+      A1.t[LL - 1][R] = fmaf(-e1[R], e1[R], e1[R]);
+    }
+    if constexpr (LL == L) { A0.aL[R] = a0[R]; A1.aL[R] = a1[R]; }
+  });
+  if constexpr (NR & 1) { a0[NR] = 0.f; a1[NR] = 0.f; }
+  sfor<0, NPK>([&](auto q) {
+    constexpr int Q = q;
+    if constexpr (Q < NPR) {
+      split_pair(a0[2 * Q], a0[2 * Q + 1], A0.hi[LL - 1][Q], A0.lo[LL - 1][Q]);
+      split_pair(a1[2 * Q], a1[2 * Q + 1], A1.hi[LL - 1][Q], A1.lo[LL - 1][Q]);
+    } else {
+      A0.hi[LL - 1][Q] = 0u; A0.lo[LL - 1][Q] = 0u;
+      A1.hi[LL - 1][Q] = 0u; A1.lo[LL - 1][Q] = 0u;
+    }
+  });
+  PF_STAGE();
+}
+
+// weights of one hidden layer as a wave reads them from the LDS image: bias vector (initial accumulator) and the
+// split A operands of both k-steps.  Loaded one phase AHEAD of their use (before the tanh stages of the previous
+// layer), so that the LDS latency hides behind the transcendentals instead of stalling the matrix products.
+struct LayerW {
+  float4 b[4];
+  h8 ahi[KS], alo[KS];
+};
+template <int LL, bool BWDOP>
+__device__ __forceinline__ void load_layer(const unsigned char* __restrict__ img, int lane, LayerW& w) {
+  const int h = lane >> 5;
+  if constexpr (!BWDOP) {
+    const float4* __restrict__ bias = reinterpret_cast<const float4*>(img + pf_n32_off_bias(LL)) + h * 4;
+    w.b[0] = bias[0]; w.b[1] = bias[1]; w.b[2] = bias[2]; w.b[3] = bias[3];
+  }
+  const h8* __restrict__ af = reinterpret_cast<const h8*>(img + (BWDOP ? pf_n32_off_ab(LL) : pf_n32_off_af(LL))) + lane;
+  sfor<0, KS>([&](auto s) { constexpr int S = s; w.ahi[S] = af[(0 * 2 + S) * 64]; w.alo[S] = af[(1 * 2 + S) * 64]; });
+}
+__device__ __forceinline__ f32x16 bias_acc(const LayerW& w) {
+  return f32x16{w.b[0].x, w.b[0].y, w.b[0].z, w.b[0].w, w.b[1].x, w.b[1].y, w.b[1].z, w.b[1].w,
+                w.b[2].x, w.b[2].y, w.b[2].z, w.b[2].w, w.b[3].x, w.b[3].y, w.b[3].z, w.b[3].w};
+}
+// the output unit's weights of this lane's units: wo[2r+h], r < NR
+__device__ __forceinline__ void load_wo(const unsigned char* __restrict__ img, int lane, float (&wv)[16]) {
+  const float4* __restrict__ wo = reinterpret_cast<const float4*>(img + pf_n32_off_wo()) + (lane >> 5) * 4;
+  sfor<0, (NR + 3) / 4>([&](auto q) {
+    constexpr int Q = q;
+    const float4 w = wo[Q];
+    wv[4 * Q] = w.x; wv[4 * Q + 1] = w.y; wv[4 * Q + 2] = w.z; wv[4 * Q + 3] = w.w;
+  });
+}
+template <int IN>
+__device__ __forceinline__ float layer1_row(const float4& w, const float (&x)[3]) {
+  // layer 1 on the vector ALU in float, the reference's order: bias, then the inputs ascending
+  float c;
+  if constexpr (IN == 3) {
+    c = fmaf(w.w, 1.0f, 0.f);
+    c = fmaf(w.x, x[0], c);
+    c = fmaf(w.y, x[1], c);
+    c = fmaf(w.z, x[2], c);
+  } else {
+    c = fmaf(w.z, 1.0f, 0.f);
+    c = fmaf(w.x, x[0], c);
+    c = fmaf(w.y, x[1], c);
+  }
+  return c;
+}
+
+// forward through the hidden layers for BOTH tiles of a task; x0 / x1 = (load factor, coordinates) of the tile's
+// element on this lane's column.  p0 / p1: this lane's partial sums of the output unit, KA * sum_r wo[2r+h] a_L[2r+h].
+template <int L, int IN, bool BWD>
+__device__ __forceinline__ void forward_tiles(const unsigned char* __restrict__ img, int lane, const float (&x0)[3],
+                                              const float (&x1)[3], TileAct<L, BWD>& A0, TileAct<L, BWD>& A1,
+                                              float& p0, float& p1, int dbg = 0, int grp = -1) {
+  const int h = lane >> 5;
+  constexpr float C2 = 2.8853900817779268f;   // 2 log2(e)
+  LayerW wl[L > 1 ? L - 1 : 1];
+  float wv[16];
+  {
+    const float4* __restrict__ w1 = reinterpret_cast<const float4*>(img + pf_n32_off_w1());
+    float4 w1v[NR];
+    sfor<0, NR>([&](auto r) { constexpr int R = r; w1v[R] = w1[R * 2 + h]; });
+    if constexpr (L >= 2) load_layer<2, false>(img, lane, wl[0]);
+    else load_wo(img, lane, wv);
+    float z0[NR], z1[NR];
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      z0[R] = layer1_row<IN>(w1v[R], x0);
+      z1[R] = layer1_row<IN>(w1v[R], x1);
+    });
+    activate2<L, BWD, 1>(A0, A1, z0, z1, C2, dbg);
+  }
+  if (grp == 1) __builtin_amdgcn_s_barrier();      // lockstep point of wave group 1 (see k_net32_forward)
+  // hidden layers 2..L on the matrix cores: z' = KA KW z, bias as the initial accumulator
+  sfor<2, L + 1>([&](auto l) {
+    constexpr int LL = l;
+    const LayerW& w = wl[LL - 2];
+    f32x16 acc0 = bias_acc(w), acc1 = acc0;
+    if (!(dbg & 8)) {
+      sfor<0, KS>([&](auto s) {
+        constexpr int S = s;
+        acc0 = mfma3(acc0, w.ahi[S], w.alo[S],
+                     as_h8(A0.hi[LL - 2][4 * S], A0.hi[LL - 2][4 * S + 1], A0.hi[LL - 2][4 * S + 2], A0.hi[LL - 2][4 * S + 3]),
+                     as_h8(A0.lo[LL - 2][4 * S], A0.lo[LL - 2][4 * S + 1], A0.lo[LL - 2][4 * S + 2], A0.lo[LL - 2][4 * S + 3]));
+      });
+      sfor<0, KS>([&](auto s) {
+        constexpr int S = s;
+        acc1 = mfma3(acc1, w.ahi[S], w.alo[S],
+                     as_h8(A1.hi[LL - 2][4 * S], A1.hi[LL - 2][4 * S + 1], A1.hi[LL - 2][4 * S + 2], A1.hi[LL - 2][4 * S + 3]),
+                     as_h8(A1.lo[LL - 2][4 * S], A1.lo[LL - 2][4 * S + 1], A1.lo[LL - 2][4 * S + 2], A1.lo[LL - 2][4 * S + 3]));
+      });
+    }
+    // next phase's weights leave now, behind the matrix products and ahead of the tanh stages
+    if constexpr (LL < L) load_layer<LL + 1, false>(img, lane, wl[LL - 1]);
+    else load_wo(img, lane, wv);
+    float z0[NR], z1[NR];
+    sfor<0, NR>([&](auto r) { constexpr int R = r; z0[R] = acc0[R]; z1[R] = acc1[R]; });
+    activate2<L, BWD, LL>(A0, A1, z0, z1, C2 / (PF_N32_KA * PF_N32_KW), dbg);
+  });
+  if (grp == 2) __builtin_amdgcn_s_barrier();
+  p0 = 0.f;
+  p1 = 0.f;
+  sfor<0, NR>([&](auto r) {
+    constexpr int R = r;
+    p0 = fmaf(wv[R], A0.aL[R], p0);
+    p1 = fmaf(wv[R], A1.aL[R], p1);
+  });
+}
+
+// tanh of the NR pre-activations of ONE tile (backward recompute): same stages as activate2
+template <int L, int LL>
+__device__ __forceinline__ void activate1(TileAct<L, true>& A, const float (&z)[NR], float cz) {
+  float e[NR];
+  PF_STAGE();
+  sfor<0, NR>([&](auto r) { constexpr int R = r; e[R] = __builtin_amdgcn_exp2f(z[R] * cz); });
+  PF_STAGE();
+  sfor<0, NR>([&](auto r) { constexpr int R = r; e[R] = __builtin_amdgcn_rcpf(e[R] + 1.0f); });
+  PF_STAGE();
   float a[2 * NPR];
   sfor<0, NR>([&](auto r) {
     constexpr int R = r;
-    const float e = __builtin_amdgcn_exp2f(z[R] * cz);
-    const float q = __builtin_amdgcn_rcpf(e + 1.0f);
-    a[R] = fmaf(-2.0f * PF_N32_KA, q, PF_N32_KA);
-    if constexpr (BWD) A.t[LL - 1][R] = fmaf(-q, q, q);
+    a[R] = fmaf(-2.0f * PF_N32_KA, e[R], PF_N32_KA);
+    A.t[LL - 1][R] = fmaf(-e[R], e[R], e[R]);
     if constexpr (LL == L) A.aL[R] = a[R];
   });
   if constexpr (NR & 1) a[NR] = 0.f;
@@ -136,69 +314,38 @@ __device__ __forceinline__ void activate(TileAct<L, BWD>& A, const float (&z)[NR
     if constexpr (Q < NPR) split_pair(a[2 * Q], a[2 * Q + 1], A.hi[LL - 1][Q], A.lo[LL - 1][Q]);
     else { A.hi[LL - 1][Q] = 0u; A.lo[LL - 1][Q] = 0u; }
   });
+  PF_STAGE();
 }
 
-// forward through the hidden layers for ONE tile; x = (load factor, coordinates) of the tile's element on this
-// lane's column.  Returns this lane's partial sum of the output unit, KA * sum_r wo[2r+h] a_L[2r+h].
-template <int L, int IN, bool BWD>
-__device__ __forceinline__ float forward_tile(const unsigned char* __restrict__ img, int lane, const float (&x)[3],
-                                              TileAct<L, BWD>& A) {
+// hidden layers of ONE tile, no output unit: what the backward pass needs (activations and their derivatives).
+// Weights are read from the LDS image where they are used: this kernel lives on its register budget (three waves
+// per SIMD), and with three waves a SIMD hides the LDS latency by itself.
+template <int L, int IN>
+__device__ __forceinline__ void recompute_tile(const unsigned char* __restrict__ img, int lane, const float (&x)[3],
+                                               TileAct<L, true>& A) {
   const int h = lane >> 5;
-  constexpr float C2 = 2.8853900817779268f;   // 2 log2(e)
-  // layer 1 on the vector ALU in float, the reference's order: bias, then the inputs ascending
+  constexpr float C2 = 2.8853900817779268f;
   {
     const float4* __restrict__ w1 = reinterpret_cast<const float4*>(img + pf_n32_off_w1());
     float z[NR];
-    sfor<0, NR>([&](auto r) {
-      constexpr int R = r;
-      const float4 w = w1[R * 2 + h];
-      float acc;
-      if constexpr (IN == 3) {
-        acc = fmaf(w.w, 1.0f, 0.f);
-        acc = fmaf(w.x, x[0], acc);
-        acc = fmaf(w.y, x[1], acc);
-        acc = fmaf(w.z, x[2], acc);
-      } else {
-        acc = fmaf(w.z, 1.0f, 0.f);
-        acc = fmaf(w.x, x[0], acc);
-        acc = fmaf(w.y, x[1], acc);
-      }
-      z[R] = acc;
-    });
-    activate<L, BWD, 1>(A, z, C2);
+    sfor<0, NR>([&](auto r) { constexpr int R = r; z[R] = layer1_row<IN>(w1[R * 2 + h], x); });
+    activate1<L, 1>(A, z, C2);
   }
-  // hidden layers 2..L on the matrix cores: z' = KA KW z, bias as the initial accumulator
   sfor<2, L + 1>([&](auto l) {
     constexpr int LL = l;
-    const float4* __restrict__ bias = reinterpret_cast<const float4*>(img + pf_n32_off_bias(LL)) + h * 4;
-    const h8* __restrict__ af = reinterpret_cast<const h8*>(img + pf_n32_off_af(LL)) + lane;
-    f32x16 acc;
-    {
-      const float4 b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
-      acc = f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
-    }
+    LayerW w;
+    load_layer<LL, false>(img, lane, w);
+    f32x16 acc = bias_acc(w);
     sfor<0, KS>([&](auto s) {
       constexpr int S = s;
-      const h8 ahi = af[(0 * 2 + S) * 64], alo = af[(1 * 2 + S) * 64];
-      const h8 bhi = as_h8(A.hi[LL - 2][4 * S], A.hi[LL - 2][4 * S + 1], A.hi[LL - 2][4 * S + 2], A.hi[LL - 2][4 * S + 3]);
-      const h8 blo = as_h8(A.lo[LL - 2][4 * S], A.lo[LL - 2][4 * S + 1], A.lo[LL - 2][4 * S + 2], A.lo[LL - 2][4 * S + 3]);
-      acc = mfma3(acc, ahi, alo, bhi, blo);
+      acc = mfma3(acc, w.ahi[S], w.alo[S],
+                  as_h8(A.hi[LL - 2][4 * S], A.hi[LL - 2][4 * S + 1], A.hi[LL - 2][4 * S + 2], A.hi[LL - 2][4 * S + 3]),
+                  as_h8(A.lo[LL - 2][4 * S], A.lo[LL - 2][4 * S + 1], A.lo[LL - 2][4 * S + 2], A.lo[LL - 2][4 * S + 3]));
     });
     float z[NR];
     sfor<0, NR>([&](auto r) { constexpr int R = r; z[R] = acc[R]; });
-    activate<L, BWD, LL>(A, z, C2 / (PF_N32_KA * PF_N32_KW));
+    activate1<L, LL>(A, z, C2 / (PF_N32_KA * PF_N32_KW));
   });
-  // output unit: this lane's share
-  const float4* __restrict__ wo = reinterpret_cast<const float4*>(img + pf_n32_off_wo()) + h * 4;
-  float wv[16];
-  sfor<0, (NR + 3) / 4>([&](auto q) {
-    constexpr int Q = q;
-    const float4 w = wo[Q];
-    wv[4 * Q] = w.x; wv[4 * Q + 1] = w.y; wv[4 * Q + 2] = w.z; wv[4 * Q + 3] = w.w;
-  });
-  float p = 0.f;
-  sfor<0, NR>([&](auto r) { constexpr int R = r; p = fmaf(wv[R], A.aL[R], p); });
-  return p;
 }
 
 template <int IN>
@@ -221,66 +368,126 @@ __device__ __forceinline__ void copy_image(unsigned char* dst, const unsigned ch
 }
 
 // ---- forward kernel ----------------------------------------------------------------------------------------
-// Each wave walks 64-element tasks.  Lanes past the end work on the last element again (same inputs, same value)
-// and do not store.
+// One block of 16 waves per CU (four per SIMD); every wave walks 64-element tasks, the block in rounds of 16 tasks.
+// The SIMD arbitrates its waves by age: left alone the oldest runs nearly unimpeded, the waves of a SIMD finish far
+// apart (measured: 26 ... 71 us for equal work) and the tail runs on one wave per SIMD.  ONE s_barrier per task
+// keeps the block's waves within a task of each other; the four wave groups (wave >> 2: one wave per SIMD each)
+// pass it at four different places of the task body, so the waves of a SIMD stay a quarter task out of phase
+// instead of reaching their transcendental, matrix and LDS phases together (MI355X_MICROARCH.md, two waves per
+// SIMD, item 9).  Lanes past the end work on the last element again (same inputs, same value) and do not store.
+constexpr int FW_THREADS = 1024;
+
 template <int L, int IN>
-__global__ __launch_bounds__(256) void k_net32_forward(pf_problem P, int which) {
+__global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg, int ws) {
   extern __shared__ __align__(16) unsigned char smem[];
   const pf_net net = P.net[which];
   copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), pf_n32_bytes(L));
   float* __restrict__ out = which == 0 ? P.prop_e : P.prop_a;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int grp = (dbg & 32) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // provably wave-uniform
   const int n = P.mesh.n_elems;
-  const int stride = gridDim.x * waves * 64;
-  int base = (blockIdx.x * waves + wv) * 64;
+  const int ntasks = (n + 63) >> 6;
+  const int per_round = gridDim.x * waves;
+  const int rounds = (ntasks + per_round - 1) / per_round;        // block-uniform trip count: equal barrier counts
+  int task = blockIdx.x * waves + wv;
   float xn[3];
-  if (n > 0) load_x<IN>(xn, P, min(base + lane, n - 1));
+  if (n > 0) load_x<IN>(xn, P, min(task * 64 + lane, n - 1));
   __syncthreads();
   if (P.state->done || n <= 0) return;
   const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
-  for (; base < n; base += stride) {
-    const int e = base + lane;
+  unsigned long long st0 = 0, sr0 = 0;
+  if (dbg & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+  for (int r = 0; r < rounds; ++r, task += per_round) {
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    const int e = task * 64 + lane;
     float x0[3], x1[3];
     sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
-    if (base + stride < n) load_x<IN>(xn, P, min(e + stride, n - 1));
+    if (r + 1 < rounds) load_x<IN>(xn, P, min(e + per_round * 64, n - 1));
     TileAct<L, false> A0, A1;
-    const float p0 = forward_tile<L, IN, false>(smem, lane, x0, A0);
-    const float p1 = forward_tile<L, IN, false>(smem, lane, x1, A1);
+    float p0, p1;
+    forward_tiles<L, IN, false>(smem, lane, x0, x1, A0, A1, p0, p1, dbg, grp);
     const float z = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo;
-    if (e < n) out[e] = (net.positive ? pf_softplus(z) : z) * net.scale;
+    if (e < n) {
+      const float v = (net.positive ? pf_softplus(z) : z) * net.scale;
+      out[e] = v;
+      if (ws) {   // element stiffness for the node kernels: (young * area) / l0, nn_assembly.py:74 (2-D), :37 (1-D)
+        const pf_net onet = P.net[1 - which];
+        const float o = onet.enabled ? (which == 0 ? P.prop_a : P.prop_e)[e] : onet.scale;
+        const float l0 = P.mesh.egeo[4 * (size_t)e + 3];
+        P.elem_s[e] = (which == 0 ? v * o : o * v) / l0;
+      }
+    }
+    if (grp == 3) __builtin_amdgcn_s_barrier();
+  }
+  if ((dbg & 16) && lane == 0) {   // diagnostic build only: per-wave stamps into the (unused here) partial-sum workspace
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(P.partials) + (size_t)(blockIdx.x * waves + wv) * 4 + (size_t)which * 65536;
+    d[0] = sr0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = __builtin_amdgcn_s_memtime() - st0;
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    d[3] = ((unsigned long long)rounds << 48) | ((unsigned long long)(xcc & 0xf) << 32) | hwid;
   }
 }
 
 // ---- backward kernel ---------------------------------------------------------------------------------------
-// LDS per wave: three regions of [2 split][2 chunk] x 1152 B: A side (d rows), B side (activation columns), X (inputs).
-// A lane writes its 16 f16 of a chunk at lane*16 + (lane>>5)*64; chunk 1 (registers 8..15) sits 1152 B further:
-// with these strides both the 16-B writes and the transposed 8-B reads are bank-conflict free.
-constexpr int CHUNK = 1152;
-constexpr int REGION = 4 * CHUNK;           // [split][chunk]
-constexpr int WAVE_SCRATCH = 3 * REGION;
+// LDS per wave: two regions, A side (rows d_l of a gradient tile) and B side (columns a_{l-1}; the inputs image of the
+// first layer's tile aliases it: its other columns then hold stale activations, which only reach tile entries that are
+// never written out).  A region holds, per split (hi, lo), the registers 0..7 of every lane ("chunk 0", 16 B per lane
+// at lane*16 + (lane>>5)*64) and the registers 8..15 ("chunk 1").  COMPACT layout (PF_NR <= 12): chunk 1 keeps only
+// registers 8..11 (8 B per lane, [element/4][half-wave][element%4]), column quad 12..15 is read from a constant block
+// (zeros; for the hi image of the B side the block that carries KA in column 15 = the bias column of the tile).
+// All strides are chosen so that the 16-B / 8-B writes and the transposed 8-B reads touch every bank once:
+// a 32-lane half reads 16 pieces of chunk 0 in [c, c+128), 8 of chunk 1 in [c+128, c+192) and 8 of the constant block
+// in [c+192, c+256) (mod 256 B), c = 128*(lane>>5) + 64*(read half).
+constexpr bool COMPACT = NR <= 12;
+constexpr int SP_STRIDE = COMPACT ? 1792 : 2304;      // hi image -> lo image
+constexpr int C1_OFF = 1152;                          // chunk 0 -> chunk 1
+constexpr int REGION = COMPACT ? 3584 : 4608;
+constexpr int WAVE_SCRATCH = 2 * REGION;
+constexpr int CONST_BYTES = 1536;                     // zero block at +192, bias block at +960 (both = 192 mod 256)
+// waves per block (one block per CU): 12 (three per SIMD, 168 registers) where the kernel fits that budget without
+// spilling — measured with -Rpass-analysis: one hidden layer, or two without the fused element adjoint — else 8.
+// A spill reload inside the task loop is followed by s_waitcnt vmcnt(0), which also waits for the NEXT task's
+// prefetched gathers: the spilling 12-wave variant ran slower than the 8-wave one.
+template <int L, bool GEA>
+constexpr int bw_threads() { return (COMPACT && (L == 1 || (L == 2 && !GEA))) ? 768 : 512; }
+constexpr int BW_MAX_THREADS = 768;
 
-__device__ __forceinline__ int lane_slot(int lane) { return lane * 16 + (lane >> 5) * 64; }
-
-// lane's pairs (hi or lo) of registers 0..15 -> its slot of the region's split `sp`
-__device__ __forceinline__ void write_rows(unsigned char* region, int sp, int lane, const unsigned (&pk)[NPK]) {
-  unsigned char* p = region + sp * 2 * CHUNK + lane_slot(lane);
-  *reinterpret_cast<u32x4*>(p) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-  if constexpr (NR > 12) *reinterpret_cast<u32x4*>(p + CHUNK) = u32x4{pk[4], pk[5], pk[6], pk[7]};
-  else if constexpr (NR > 8) *reinterpret_cast<u32x2*>(p + CHUNK) = u32x2{pk[4], pk[5]};
+// lane's pairs (hi or lo) of registers 0..15 -> the region's split `sp`.  bias_col: wide layout only, B side hi image:
+// the lane's register 15 carries the bias column's KA (lower half-wave)
+__device__ __forceinline__ void write_rows(unsigned char* region, int sp, int lane, const unsigned (&pk)[NPK],
+                                           bool bias_col = false) {
+  const int hs = lane >> 5, e = lane & 31;
+  unsigned char* p = region + sp * SP_STRIDE;
+  *reinterpret_cast<u32x4*>(p + hs * 576 + e * 16) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+  if constexpr (!COMPACT) {
+    const unsigned k7 = pk[7] | ((bias_col && hs == 0) ? 0x68000000u : 0u);      // f16 2048.0 in the high half
+    *reinterpret_cast<u32x4*>(p + C1_OFF + hs * 576 + e * 16) = u32x4{pk[4], pk[5], pk[6], k7};
+  } else if constexpr (NR > 8) {
+    *reinterpret_cast<u32x2*>(p + C1_OFF + 64 * (e >> 2) + 32 * hs + 8 * (e & 3)) = u32x2{pk[4], pk[5]};
+  }
 }
 
-// MFMA operand (A: rows = image columns, B: columns = image columns; k = 16 elements of step ks) read transposed.
-// Group g = lane>>4 reads the 4x16 block rows (elements) e0..e0+3, columns 16*(g&1)..+15; lane 4q+p of the
-// group supplies the address of row q, columns 4p..4p+3 (cdna_hip_programming.md T10).
-__device__ __forceinline__ h8 read_operand(const unsigned char* region, int sp, int ks, int lane) {
+// Per-lane base address of the transposed operand reads of one image (cdna_hip_programming.md T10): group g = lane>>4
+// reads the 4x16 block rows (elements) e0..e0+3, columns 16*(g&1)..+15; lane 4q+p of the group supplies the address of
+// row q, columns 4p..4p+3.  The element part 16*e0 = 256*ks + 64*half (+128*(lane>>5), folded in here) is the same for
+// every lane, so the reads of a tile use immediate offsets.
+__device__ __forceinline__ const unsigned char* operand_base(const unsigned char* region, int sp, int lane,
+                                                             const unsigned char* p3block) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
   const int hsrc = g & 1, hl = g >> 1;
-  const unsigned char* base = region + sp * 2 * CHUNK + (p >> 1) * CHUNK + hsrc * (32 * 16 + 64) + 8 * (p & 1);
-  const int e0 = 16 * ks + 8 * hl + q;
-  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s4v*)(base + e0 * 16));
-  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s4v*)(base + (e0 + 4) * 16));
+  const unsigned char* img = region + sp * SP_STRIDE;
+  const unsigned char* a;
+  if constexpr (COMPACT) {
+    a = p < 2 ? img + hsrc * 576 + q * 16 + 8 * (p & 1)
+              : (p == 2 ? img + C1_OFF + 32 * hsrc + 8 * q : p3block + 32 * hsrc + 8 * q);
+  } else {
+    a = img + (p >> 1) * C1_OFF + hsrc * 576 + q * 16 + 8 * (p & 1);
+  }
+  return a + 128 * hl;
+}
+__device__ __forceinline__ h8 read_operand(const unsigned char* base, int ks) {
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + 256 * ks));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + 256 * ks + 64));
   typedef short s8v __attribute__((ext_vector_type(8)));
   return __builtin_bit_cast(h8, s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
@@ -288,7 +495,7 @@ __device__ __forceinline__ h8 read_operand(const unsigned char* region, int sp, 
 template <int DIM>
 struct TaskIn {
   float x[3];
-  float oth, gea;
+  float oth, own, gea;
   int2 nn;
   ElemGeo g;
   float ui[2], uj[2], gi[2], gj[2];
@@ -296,9 +503,10 @@ struct TaskIn {
 
 template <int IN, bool GEA>
 __device__ __forceinline__ void task_fetch_a(TaskIn<IN - 1>& t, const pf_problem& P, const pf_net& onet,
-                                             const float* __restrict__ other, int e) {
+                                             const float* __restrict__ other, const float* __restrict__ mine, int e) {
   load_x<IN>(t.x, P, e);
   t.oth = onet.enabled ? other[e] : onet.scale;
+  t.own = mine[e];
   t.gea = 0.f;
   if (GEA) {
     t.nn = reinterpret_cast<const int2*>(P.mesh.conn)[e];
@@ -336,25 +544,22 @@ __device__ __forceinline__ float task_gea(const TaskIn<DIM>& t, int fe_mode) {
 
 // backward of one tile: d_L from g_z S, back-propagation, and the tile's contribution to the gradient products
 // T[0] = combined tile (rows d_1, columns inputs), T[l-1] = rows d_l, columns a_{l-1} (l = 2..L).
+// wv: wo of this lane's units; wb: transposed operands of layer L (both loaded by recompute_tile).
 template <int L, int IN>
 __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ img, unsigned char* scratch, int lane,
                                               const TileAct<L, true>& A, float gs /* g_z S of the column's element */,
                                               const unsigned (&xhi)[NPK], const unsigned (&xlo)[NPK],
-                                              f32x16 (&T)[L]) {
+                                              f32x16 (&T)[L],
+                                              const unsigned char* const (&rd)[4] /* A hi, A lo, B hi, B lo */,
+                                              const unsigned char* rdBhi_in /* B hi with the zero block */, int dbg = 0) {
   const int h = lane >> 5;
   unsigned char* regA = scratch;
   unsigned char* regB = scratch + REGION;
-  unsigned char* regX = scratch + 2 * REGION;
   // d_L[r] = (4 wo[2r+h] g_z S) t_L[r]
   float d[2 * NPR];
   {
-    const float4* __restrict__ wo = reinterpret_cast<const float4*>(img + pf_n32_off_wo()) + h * 4;
     float wv[16];
-    sfor<0, (NR + 3) / 4>([&](auto q) {
-      constexpr int Q = q;
-      const float4 w = wo[Q];
-      wv[4 * Q] = w.x; wv[4 * Q + 1] = w.y; wv[4 * Q + 2] = w.z; wv[4 * Q + 3] = w.w;
-    });
+    load_wo(img, lane, wv);
     const float g4 = 4.0f * gs;
     sfor<0, NR>([&](auto r) { constexpr int R = r; d[R] = (wv[R] * g4) * A.t[L - 1][R]; });
     if constexpr (NR & 1) d[NR] = 0.f;
@@ -367,175 +572,170 @@ __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ 
       if constexpr (Q < NPR) split_pair(d[2 * Q], d[2 * Q + 1], dhi[Q], dlo[Q]);
       else { dhi[Q] = 0u; dlo[Q] = 0u; }
     });
-    // gradient tile of layer LL: rows d_LL through LDS; columns a_{LL-1} (LL >= 2) or the inputs (LL == 1)
-    write_rows(regA, 0, lane, dhi);
-    write_rows(regA, 1, lane, dlo);
-    unsigned char* regC = regX;
-    if constexpr (LL >= 2) {
-      write_rows(regB, 0, lane, A.hi[LL - 2]);
-      write_rows(regB, 1, lane, A.lo[LL - 2]);
-      regC = regB;
-    } else {
-      // inputs of the element: registers 0..3 of the lower half-wave's slot (columns 0..3)
-      if (h == 0) {
-        *reinterpret_cast<u32x2*>(regX + lane_slot(lane)) = u32x2{xhi[0], xhi[1]};
-        *reinterpret_cast<u32x2*>(regX + 2 * CHUNK + lane_slot(lane)) = u32x2{xlo[0], xlo[1]};
-      }
-    }
-    // back-propagation to layer LL-1 while the LDS round trip is in flight
+    // back-propagation to layer LL-1 first: it is the critical path (d_{LL-1} feeds the next layer)
     f32x16 acc = zero16();
     if constexpr (LL >= 2) {
-      const h8* __restrict__ ab = reinterpret_cast<const h8*>(img + pf_n32_off_ab(LL)) + lane;
+      LayerW w;
+      load_layer<LL, true>(img, lane, w);
       sfor<0, KS>([&](auto ks) {
         constexpr int S = ks;
-        const h8 ahi = ab[(0 * 2 + S) * 64], alo = ab[(1 * 2 + S) * 64];
-        const h8 bhi = as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]);
-        const h8 blo = as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]);
-        acc = mfma3(acc, ahi, alo, bhi, blo);
+        acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
+                    as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
       });
     }
-    // the wave's own LDS writes are visible to its own later reads (in-order); tell the compiler only
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    sfor<0, 2>([&](auto ks) {
-      constexpr int S = ks;
-      const h8 ahi = read_operand(regA, 0, S, lane), alo = read_operand(regA, 1, S, lane);
-      const h8 bhi = read_operand(regC, 0, S, lane), blo = read_operand(regC, 1, S, lane);
-      T[LL - 1] = mfma3(T[LL - 1], ahi, alo, bhi, blo);
-    });
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // gradient tile of layer LL: rows d_LL through LDS; columns a_{LL-1} (LL >= 2) or the inputs (LL == 1)
+    if (!(dbg & 1)) {
+      write_rows(regA, 0, lane, dhi);
+      write_rows(regA, 1, lane, dlo);
+      if constexpr (LL >= 2) {
+        write_rows(regB, 0, lane, A.hi[LL - 2], true);
+        write_rows(regB, 1, lane, A.lo[LL - 2]);
+      } else {
+        // inputs of the element: registers 0..3 of the lower half-wave's slot (columns 0..3) of the B region
+        if (h == 0) {
+          *reinterpret_cast<u32x2*>(regB + lane * 16) = u32x2{xhi[0], xhi[1]};
+          *reinterpret_cast<u32x2*>(regB + SP_STRIDE + lane * 16) = u32x2{xlo[0], xlo[1]};
+        }
+      }
+      // the wave's own LDS writes are visible to its own later reads (in-order); tell the compiler only
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      sfor<0, 2>([&](auto ks) {
+        constexpr int S = ks;
+        const h8 ahi = read_operand(rd[0], S), alo = read_operand(rd[1], S);
+        const h8 bhi = read_operand(LL >= 2 ? rd[2] : rdBhi_in, S), blo = read_operand(rd[3], S);
+        T[LL - 1] = mfma3(T[LL - 1], ahi, alo, bhi, blo);
+      });
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     if constexpr (LL >= 2) {
       sfor<0, NR>([&](auto r) { constexpr int R = r; d[R] = acc[R] * A.t[LL - 2][R]; });
     }
   });
 }
 
-constexpr int BW_THREADS = 512;
-
 // GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the other net's
 // backward.  Partial gradient row of the block: the padded image of pf_common.h (what theta_stage1 sums).
 template <int L, int IN, bool GEA>
-__global__ __launch_bounds__(BW_THREADS, 2) void k_net32_backward(pf_problem P, int which, int hp) {
+__global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_problem P, int which, int hp, int dbg) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int DIM = IN - 1;
   constexpr int IMG = pf_n32_bytes(L);
   const pf_net net = P.net[which];
   const pf_net onet = P.net[1 - which];
   const float* __restrict__ other = which == 0 ? P.prop_a : P.prop_e;
+  const float* __restrict__ mine = which == 0 ? P.prop_e : P.prop_a;   // this net's forward values (pf_net_forward)
   const int n = P.mesh.n_elems;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const int h = lane >> 5;
   copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), IMG);
-  unsigned char* scratch = smem + ((IMG + 127) & ~127) + wv * WAVE_SCRATCH;
-  // zero the scratch (padding columns stay zero for the whole kernel), then the bias column of the B region:
-  // KA in column 15 of the lower half-wave's slots (hi image, chunk 1, bytes 14..15)
+  constexpr int IMGPAD = (IMG + 255) & ~255;
+  unsigned char* cst = smem + IMGPAD;                  // constant blocks: zeros at +192, bias column block at +960
+  unsigned char* scratch = smem + IMGPAD + CONST_BYTES + wv * WAVE_SCRATCH;
+  for (int i = threadIdx.x; i < CONST_BYTES / 4; i += blockDim.x) reinterpret_cast<unsigned*>(cst)[i] = 0u;
   for (int i = lane; i < WAVE_SCRATCH / 16; i += 64) reinterpret_cast<uint4*>(scratch)[i] = make_uint4(0, 0, 0, 0);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (h == 0) *reinterpret_cast<_Float16*>(scratch + REGION + CHUNK + lane_slot(lane) + 14) = (_Float16)PF_N32_KA;
+  __syncthreads();
+  // bias block: [element/4][half-wave][element%4] x (registers 12..15 as f16): KA in register 15 of the lower half-wave
+  if (threadIdx.x < 32) *reinterpret_cast<_Float16*>(cst + 960 + 64 * (threadIdx.x >> 2) + 8 * (threadIdx.x & 3) + 6) = (_Float16)PF_N32_KA;
+  const unsigned char* rd[4] = {operand_base(scratch, 0, lane, cst + 192), operand_base(scratch, 1, lane, cst + 192),
+                                operand_base(scratch + REGION, 0, lane, cst + 960), operand_base(scratch + REGION, 1, lane, cst + 192)};
+  const unsigned char* rdBhi_in = operand_base(scratch + REGION, 0, lane, cst + 192);   // inputs image: no bias column
 
   const int stride = gridDim.x * waves * 64;
   int base = (blockIdx.x * waves + wv) * 64;
   TaskIn<DIM> nxt;
-  if (n > 0) task_fetch_a<IN, GEA>(nxt, P, onet, other, min(base + lane, n - 1));
+  if (n > 0) task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(base + lane, n - 1));
   __syncthreads();
   if (P.state->done != 0 || n <= 0) return;      // block-uniform
   task_fetch_b<IN, GEA>(nxt, P);
 
   const float bound = reinterpret_cast<const float*>(smem)[0];
-  const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
   const float kx = __builtin_ldexpf(1.0f, P.coord_exp);
-  f32x16 T[L];          // sum over tasks of (tile products) / S
+  const float inv_scale = 1.0f / net.scale;
+  f32x16 T[L];          // sum over this wave's tasks of S * (tile products); S = Srun, a power of two that only falls
   sfor<0, L>([&](auto l) { constexpr int LL = l; T[LL] = zero16(); });
+  float Srun = 0.f;     // 0: not chosen yet
   float go[NR];         // sum over own-column elements of g_z a'_L[r]
   sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = 0.f; });
   float gbo = 0.f;      // sum over own elements of g_z
 
-  {
-    for (; base < n; base += stride) {
-      const int e = base + lane;
-      const bool live = e < n;
-      const TaskIn<DIM> cur = nxt;
-      const bool more = base + stride < n;
-      if (more) task_fetch_a<IN, GEA>(nxt, P, onet, other, min(e + stride, n - 1));
-      // ---- forward recompute of both tiles ---------------------------------------------------------------
-      float x0[3], x1[3];
-      sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(cur.x[C], x0[C], x1[C]); });
-      TileAct<L, true> A0, A1;
-      const float p0 = forward_tile<L, IN, true>(smem, lane, x0, A0);
-      const float p1 = forward_tile<L, IN, true>(smem, lane, x1, A1);
-      const float z = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo;
-      if (more) task_fetch_b<IN, GEA>(nxt, P);
-      // ---- per-element scalars: one element per lane ----------------------------------------------------------
-      float gz = 0.f;
-      if (live) {
-        float gea;
-        if (GEA) {
-          gea = task_gea<DIM>(cur, P.fe_mode);
-          P.g_ea[e] = gea;
-        } else {
-          gea = cur.gea;
-        }
-        float g = gea * cur.oth;   // mul backward of young*area        (nn_assembly.py:74)
-        g = g * net.scale;         // output*scale backward              (properties.py:156)
-        gz = net.positive ? g * pf_softplus_grad(z) : g;
+  for (; base < n; base += stride) {
+    const int e = base + lane;
+    const bool live = e < n;
+    const TaskIn<DIM> cur = nxt;
+    const bool more = base + stride < n;
+    if (more) task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(e + stride, n - 1));
+    // ---- per-element scalars: one element per lane ----------------------------------------------------------
+    // softplus'(z) = sigmoid(z) = 1 - exp(-softplus(z)) from the forward's stored value (= softplus(z) * scale), so the
+    // output unit need not be recomputed (torch: z > 20 ? 1 : e^z / (e^z + 1), the same number to float round-off)
+    float gz = 0.f;
+    if (live) {
+      float gea;
+      if (GEA) {
+        gea = task_gea<DIM>(cur, P.fe_mode);
+        P.g_ea[e] = gea;
+      } else {
+        gea = cur.gea;
       }
-      // power-of-two scale of this task: max |d| S <= 2^14
-      const float gmax = wave_max(fabsf(gz)) * bound;
-      int ex = 0;
-      if (gmax > 0.f && gmax < 3.0e38f) (void)frexpf(gmax, &ex);
-      ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
-      const float S = __builtin_ldexpf(1.0f, 14 - ex), invS = __builtin_ldexpf(1.0f, ex - 14);
-      const float gzS = gz * S;
-      float gs0, gs1;
-      both_tiles(gzS, gs0, gs1);
-      // inputs of the combined tile: (KL lam, kx x, kx y, 1) resp. (KL lam, kx x, 1, 0), own element
-      unsigned xhi[NPK], xlo[NPK];
-      {
-        const float i0 = PF_N32_KL * cur.x[0], i1 = kx * cur.x[1];
-        const float i2 = IN == 3 ? kx * cur.x[2] : 1.0f, i3 = IN == 3 ? 1.0f : 0.f;
-        split_pair(i0, i1, xhi[0], xlo[0]);
-        split_pair(i2, i3, xhi[1], xlo[1]);
-        sfor<2, NPK>([&](auto q) { constexpr int Q = q; xhi[Q] = 0u; xlo[Q] = 0u; });
-      }
-      // the inputs image wants, in the LOWER half-wave's slot c, the inputs of the tile's element c
-      unsigned xh0[NPK], xl0[NPK], xh1[NPK], xl1[NPK];
-      sfor<0, NPK>([&](auto q) { constexpr int Q = q; xh0[Q] = xl0[Q] = xh1[Q] = xl1[Q] = 0u; });
-      sfor<0, 2>([&](auto q) {
-        constexpr int Q = q;
-        float a0, a1;
-        both_tiles(__builtin_bit_cast(float, xhi[Q]), a0, a1);
-        xh0[Q] = __builtin_bit_cast(unsigned, a0); xh1[Q] = __builtin_bit_cast(unsigned, a1);
-        both_tiles(__builtin_bit_cast(float, xlo[Q]), a0, a1);
-        xl0[Q] = __builtin_bit_cast(unsigned, a0); xl1[Q] = __builtin_bit_cast(unsigned, a1);
-      });
-      // ---- backward of both tiles into fresh product tiles ---------------------------------------------------------
-      f32x16 F[L];
-      sfor<0, L>([&](auto l) { constexpr int LL = l; F[LL] = zero16(); });
-      backward_tile<L, IN>(smem, scratch, lane, A0, gs0, xh0, xl0, F);
-      backward_tile<L, IN>(smem, scratch, lane, A1, gs1, xh1, xl1, F);
-      sfor<0, L>([&](auto l) {
-        constexpr int LL = l;
-        sfor<0, 16>([&](auto i) { constexpr int I = i; T[LL][I] = fmaf(F[LL][I], invS, T[LL][I]); });
-      });
-      // output unit: g_z a'_L, the lane's share of both tiles
-      const float g0 = gs0 * invS, g1 = gs1 * invS;
-      sfor<0, NR>([&](auto r) {
-        constexpr int R = r;
-        go[R] = fmaf(g0, A0.aL[R], go[R]);
-        go[R] = fmaf(g1, A1.aL[R], go[R]);
-      });
-      gbo += gz;
+      float g = gea * cur.oth;   // mul backward of young*area        (nn_assembly.py:74)
+      g = g * net.scale;         // output*scale backward              (properties.py:156)
+      gz = net.positive ? g * (-expm1f(-(cur.own * inv_scale))) : g;
     }
+    if (more) task_fetch_b<IN, GEA>(nxt, P);
+    // power-of-two scale: max |d| S <= 2^14 with the weight bound of the image header; S only ever falls, T follows
+    {
+      const float gmax = wave_max(fabsf(gz)) * bound;
+      if (gmax > 0.f && gmax < 3.0e38f) {
+        int ex = 0;
+        (void)frexpf(gmax, &ex);
+        ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+        const float Sneed = __builtin_ldexpf(1.0f, 14 - ex);
+        if (Srun == 0.f) Srun = Sneed;
+        else if (Sneed < Srun) {
+          const float f = Sneed / Srun;      // exact: powers of two
+          sfor<0, L>([&](auto l) {
+            constexpr int LL = l;
+            sfor<0, 16>([&](auto i) { constexpr int I = i; T[LL][I] *= f; });
+          });
+          Srun = Sneed;
+        }
+      }
+    }
+    const float S = Srun == 0.f ? 1.0f : Srun;
+    float g0, g1;
+    both_tiles(gz, g0, g1);
+    float xa0, xa1, xb0, xb1;
+    both_tiles(cur.x[1], xa0, xa1);
+    both_tiles(cur.x[2], xb0, xb1);
+    // ---- the two tiles, one after the other ------------------------------------------------------------------
+    sfor<0, 2>([&](auto tt) {
+      constexpr int TT = tt;
+      const float xt[3] = {cur.x[0], TT ? xa1 : xa0, TT ? xb1 : xb0};
+      const float gt = TT ? g1 : g0;
+      TileAct<L, true> A;
+      recompute_tile<L, IN>(smem, lane, xt, A);
+      // inputs of the combined tile: (KL lam, kx x, kx y, 1) resp. (KL lam, kx x, 1, 0)
+      unsigned xhi[NPK], xlo[NPK];
+      sfor<2, NPK>([&](auto q) { constexpr int Q = q; xhi[Q] = 0u; xlo[Q] = 0u; });
+      split_pair(PF_N32_KL * xt[0], kx * xt[1], xhi[0], xlo[0]);
+      split_pair(IN == 3 ? kx * xt[2] : 1.0f, IN == 3 ? 1.0f : 0.f, xhi[1], xlo[1]);
+      if (!(dbg & 2)) backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, rd, rdBhi_in, dbg);
+      sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = fmaf(gt, A.aL[R], go[R]); });
+    });
+    gbo += gz;
   }
+  const float invS = Srun == 0.f ? 1.0f : 1.0f / Srun;
+  sfor<0, L>([&](auto l) {
+    constexpr int LL = l;
+    sfor<0, 16>([&](auto i) { constexpr int I = i; T[LL][I] *= invS; });
+  });
 
   // ---- write-out: fixed-order sums over the block's waves -> this block's partial gradient row ---------------------------
   __syncthreads();
-  float* stage = reinterpret_cast<float*>(smem + ((IMG + 127) & ~127));   // reuses the scratch: [wave][1024]
+  float* stage = reinterpret_cast<float*>(smem + IMGPAD + CONST_BYTES);   // reuses the scratch: [wave][1024]
   const int W = net.width;
   float* __restrict__ prow = P.partials + PF_PART_WG + (size_t)blockIdx.x * P.pad_total + net.pad_off;
   const int padc = pf_pad_count(hp, L);
@@ -605,11 +805,13 @@ __global__ __launch_bounds__(BW_THREADS, 2) void k_net32_backward(pf_problem P, 
 template <int L, int IN>
 int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
   const int n = p->mesh.n_elems;
-  int nb = (n + 255) / 256;
-  static const int cap = getenv("PF_FWD32_BLOCKS") ? atoi(getenv("PF_FWD32_BLOCKS")) : 1024;
+  int nb = (n + FW_THREADS - 1) / FW_THREADS;
+  static const int cap = getenv("PF_FWD32_BLOCKS") ? atoi(getenv("PF_FWD32_BLOCKS")) : 256;   // one block per CU
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL((k_net32_forward<L, IN>), dim3(nb), dim3(256), pf_n32_bytes(L), s, *p, which);
+  static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;   // timing experiments only
+  const int ws = p->elem_s != nullptr ? 1 : 0;
+  hipLaunchKernelGGL((k_net32_forward<L, IN>), dim3(nb), dim3(FW_THREADS), pf_n32_bytes(L), s, *p, which, dbg, ws);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 
@@ -617,9 +819,11 @@ template <int L, int IN, bool GEA>
 int launch_bwd_t(const pf_problem* p, int which, hipStream_t s) {
   const int nb = pf_net_blocks(p);
   const int hp = ((p->net[which].width + 3) / 4) * 4;
-  const size_t lds = ((pf_n32_bytes(L) + 127) & ~127) + (size_t)(BW_THREADS / 64) * WAVE_SCRATCH;
+  constexpr int BW_THREADS = bw_threads<L, GEA>();
+  const size_t lds = ((pf_n32_bytes(L) + 255) & ~255) + CONST_BYTES + (size_t)(BW_THREADS / 64) * WAVE_SCRATCH;
   static_assert(WAVE_SCRATCH >= 4096 + 512, "write-out staging must fit the wave scratch");
-  hipLaunchKernelGGL((k_net32_backward<L, IN, GEA>), dim3(nb), dim3(BW_THREADS), lds, s, *p, which, hp);
+  static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;   // timing experiments only
+  hipLaunchKernelGGL((k_net32_backward<L, IN, GEA>), dim3(nb), dim3(BW_THREADS), lds, s, *p, which, hp, dbg);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>

@@ -152,6 +152,9 @@ class HipEngine:
         # uses the first
         self.prop_e = torch.zeros(2 * ne, **f32)
         self.prop_a = torch.zeros(2 * ne, **f32)
+        # element stiffness (E*A)/l0 written by the MFMA32 forward pass for the node kernels (two halves, like the properties)
+        self.elem_s = (torch.zeros(2 * ne, **f32)
+                       if self.wg_mode == _capi.PF_WG_MFMA32 and any(sp.enabled for sp in self.specs) else None)
         self.g_f = torch.zeros(nd, **f32)
         self.g_ea = torch.zeros(ne, **f32)
         self.grad_u = torch.zeros(nd, **f32)
@@ -236,6 +239,7 @@ class HipEngine:
         P.net_op = self.net_op.data_ptr() if self.wg_mode == _capi.PF_WG_MFMA32 else None
         P.op_off[0], P.op_off[1] = self._op_off
         P.coord_exp = self.coord_exp
+        P.elem_s = self.elem_s.data_ptr() if self.elem_s is not None else None
         self._configured = True
 
     def _ref(self):
