@@ -47,6 +47,8 @@ extern "C" {
 #define PF_WG_MFMA32 3  /* v_mfma_f32_32x32x16_f16 with 2-way split operands (f32-grade products on the f16 matrix
                            cores; default for widths <= PF_N32_WIDTH_MAX) */
 #define PF_N32_WIDTH_MAX 30
+#define PF_MLP_F32 0
+#define PF_MLP_BF16 1
 
 /* element-force formulations */
 #define PF_FE_REFERENCE 0 /* 4-term dot per row, the reference's order (nn_assembly.py:96-100) */
@@ -159,7 +161,9 @@ typedef struct pf_problem {
   int32_t op_off[2];
   /* 2^coord_exp * max |centroid coordinate| <= 2^14: scale of the coordinates inside the f16 gradient products */
   int32_t coord_exp;
-  int32_t _pad2;
+  /* MFMA32 engine, precision of the hidden-layer and gradient matrix products: PF_MLP_F32 (2-way split f16
+   * operands, float32-grade; default) or PF_MLP_BF16 (plain bf16 operands, f32 accumulate) */
+  int32_t mlp_dtype;
   /* element stiffness s = (E*A)/l0 [n_elems] (2*n_elems with prop_double), written by the MFMA32 forward pass
    * of the LAST evaluated net (same float operations as nn_assembly.py:74) and read by the node kernels instead of
    * E, A and l0; NULL: the node kernels compute it from prop_e / prop_a / the constant properties */

@@ -16,6 +16,7 @@ PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_DOF_FIXED, PF_DOF_MEASURED, PF_DOF_SHARED, PF_DOF_GHOST = 1, 2, 4, 8
 PF_WG_SHUFFLE, PF_WG_MFMA, PF_WG_MFMA44, PF_WG_MFMA32 = 0, 1, 2, 3
 PF_N32_WIDTH_MAX = 30
+PF_MLP_F32, PF_MLP_BF16 = 0, 1
 PF_FE_REFERENCE, PF_FE_DELTA = 0, 1
 PF_HIST_COLS = 6
 PF_MAX_BLOCKS = 1024
@@ -82,7 +83,7 @@ class PfProblem(C.Structure):
         ("shared_dofs", C.c_void_p), ("shared_slot", C.c_void_p),
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
         ("iface_elems", C.c_void_p), ("n_iface_elems", C.c_int32), ("prop_double", C.c_int32),
-        ("net_op", C.c_void_p), ("op_off", C.c_int32 * 2), ("coord_exp", C.c_int32), ("_pad2", C.c_int32),
+        ("net_op", C.c_void_p), ("op_off", C.c_int32 * 2), ("coord_exp", C.c_int32), ("mlp_dtype", C.c_int32),
         ("elem_s", C.c_void_p),
     ]
 

@@ -76,7 +76,8 @@ def parse_problem(problem_file):
     # ---- build-only extension, namespaced so that reference JSONs stay valid -----------
     # "accel": {"synthetic_chain": {"n_elements": N, "h": 1.0, "tip_load": 1.0},   mesh generator
     #           "compact_output": true|false|"auto",  big arrays -> <stem>.res.npz instead of JSON lists
-    #           "fe_mode": "reference"|"delta"}       element-force formulation
+    #           "fe_mode": "reference"|"delta",       element-force formulation
+    #           "mlp_dtype": "f32"|"bf16"}            precision of the MLP matrix products (bf16 study)
     accel = data.get("accel", {})
     chain = accel.get("synthetic_chain")
     if chain and not data.get("nodes"):
@@ -169,6 +170,8 @@ def parse_problem(problem_file):
     log_print("[DEBUG] parse_problem completed successfully", level="debug")
     if accel.get("fe_mode") == "delta":
         model._pf_fe_mode = 1
+    if accel.get("mlp_dtype"):
+        model._pf_mlp_dtype = str(accel["mlp_dtype"])
     return {"model": model, "solver_config": solver_config, "measured_data": measured_data,
             "accel": accel}
 
@@ -223,6 +226,8 @@ def _parse_synthetic_chain(data, accel, chain):
                      dimension=2)
     if accel.get("fe_mode") == "delta":
         model._pf_fe_mode = 1
+    if accel.get("mlp_dtype"):
+        model._pf_mlp_dtype = str(accel["mlp_dtype"])
     measured = {}
     if data.get("solver_type", "fem").startswith("pinn") and chain.get("measure_every_node", True):
         measured = {"dofs": md, "values": mv}

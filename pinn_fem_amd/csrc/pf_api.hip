@@ -84,6 +84,7 @@ static int check_problem(const pf_problem* p) {
       if (n.width > PF_N32_WIDTH_MAX)
         return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine supports widths up to 30 (use PF_WG_MFMA44 beyond)");
       if (!p->net_op) return fail(PF_ERR_ARG, "MFMA32 engine needs the operand image workspace (net_op)");
+      if (p->mlp_dtype != PF_MLP_F32 && p->mlp_dtype != PF_MLP_BF16) return fail(PF_ERR_ARG, "mlp_dtype must be PF_MLP_F32 or PF_MLP_BF16");
     }
   }
   return PF_OK;
@@ -128,6 +129,7 @@ static int net_forward(const pf_problem* p, int which, hipStream_t s, int write_
 static int net_forward_impl(const pf_problem* p, int which, hipStream_t s) {
   // PF_FWD_F16=1: the split-f16 forward kernel (pf_net16.hip) in place of the 4x4x1 f32 one
   static const bool fwd16 = getenv("PF_FWD_F16") && atoi(getenv("PF_FWD_F16")) != 0;
+  if (p->wg_mode == PF_WG_MFMA32 && p->mlp_dtype == PF_MLP_BF16) { PF_NR_SWITCH(pf_launch_net32b_forward_) }
   if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_forward_) }
   if (p->wg_mode == PF_WG_MFMA44 && fwd16) return net_forward16(p, which, s);
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_forward_) }
@@ -135,6 +137,7 @@ static int net_forward_impl(const pf_problem* p, int which, hipStream_t s) {
 }
 
 static int net_backward(const pf_problem* p, int which, hipStream_t s) {
+  if (p->wg_mode == PF_WG_MFMA32 && p->mlp_dtype == PF_MLP_BF16) { PF_NR_SWITCH(pf_launch_net32b_backward_) }
   if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_backward_) }
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_backward_) }
   PF_WIDTH_SWITCH(pf_launch_net_backward_)
@@ -142,6 +145,7 @@ static int net_backward(const pf_problem* p, int which, hipStream_t s) {
 
 // backward that also computes and stores the element adjoint g_ea (MFMA44 engine only)
 static int net_backward_gea(const pf_problem* p, int which, hipStream_t s) {
+  if (p->wg_mode == PF_WG_MFMA32 && p->mlp_dtype == PF_MLP_BF16) { PF_NR_SWITCH(pf_launch_net32b_backward_gea_) }
   if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_backward_gea_) }
   PF_WIDTH_SWITCH(pf_launch_net44_backward_gea_)
 }

@@ -256,7 +256,10 @@ PF_DECL_NET_LAUNCHERS(32)
 #define PF_DECL_NET32_LAUNCHERS(NRB)                                                       \
   int pf_launch_net32_forward_##NRB(const pf_problem* p, int which, hipStream_t s);       \
   int pf_launch_net32_backward_##NRB(const pf_problem* p, int which, hipStream_t s);      \
-  int pf_launch_net32_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s);
+  int pf_launch_net32_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s);  \
+  int pf_launch_net32b_forward_##NRB(const pf_problem* p, int which, hipStream_t s);      \
+  int pf_launch_net32b_backward_##NRB(const pf_problem* p, int which, hipStream_t s);     \
+  int pf_launch_net32b_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s);
 PF_DECL_NET32_LAUNCHERS(2)
 PF_DECL_NET32_LAUNCHERS(4)
 PF_DECL_NET32_LAUNCHERS(6)

@@ -235,7 +235,8 @@ __device__ __forceinline__ void pack_net_ops(const pf_problem& P, const float* t
   if (P.wg_mode != PF_WG_MFMA32 || !P.net_op) return;
   for (int k = 0; k < 2; ++k) {
     if (!P.net[k].enabled) continue;
-    pf_n32_pack(P.net[k], th + P.net[k].theta_off, reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]), scratch64);
+    pf_n32_pack(P.net[k], th + P.net[k].theta_off, reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]), scratch64,
+                P.mlp_dtype);
   }
 }
 

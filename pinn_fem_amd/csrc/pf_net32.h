@@ -32,7 +32,8 @@ __host__ __device__ constexpr int pf_n32_bytes(int n_hidden) { return pf_n32_off
 
 // Build the image of net `which` from its parameters `th` (torch parameters() order: W1 [w][in], b1, (Wl [w][w],
 // bl)*, Wo [1][w], bo).  Called by every thread of one block; `scratch` = 64 floats of LDS.  Contains barriers.
-__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, float* scratch) {
+// prec 0: split f16 (hi, lo); prec 1: plain bf16 in the hi slots (round to nearest), lo slots zero.
+__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, float* scratch, int prec) {
   const int W = net.width, L = net.n_hidden, IN = net.in_dim;
   const int o_b1 = W * IN, o_h = W * IN + W, per = W * W + W, o_wo = o_h + (L - 1) * per, o_bo = o_wo + W;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -72,9 +73,15 @@ __device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned 
         vf = PF_N32_KW * Wl[u_row * W + u_k];     // z_l[u_row]   += W_l[u_row][u_k] a_{l-1}[u_k]
         vb = PF_N32_KB * Wl[u_k * W + u_row];     // dh_{l-1}[u_row] += W_l[u_k][u_row] d_l[u_k]
       }
-      const _Float16 fh = (_Float16)vf, bh = (_Float16)vb;
-      af[i] = sp ? (_Float16)(vf - (float)fh) : fh;
-      ab[i] = sp ? (_Float16)(vb - (float)bh) : bh;
+      if (prec == 1) {
+        const __bf16 fb = (__bf16)vf, bb = (__bf16)vb;
+        reinterpret_cast<unsigned short*>(af)[i] = sp ? (unsigned short)0 : __builtin_bit_cast(unsigned short, fb);
+        reinterpret_cast<unsigned short*>(ab)[i] = sp ? (unsigned short)0 : __builtin_bit_cast(unsigned short, bb);
+      } else {
+        const _Float16 fh = (_Float16)vf, bh = (_Float16)vb;
+        af[i] = sp ? (_Float16)(vf - (float)fh) : fh;
+        ab[i] = sp ? (_Float16)(vb - (float)bh) : bh;
+      }
     }
   }
   // bound for the backward scaling: v_L[j] = |wo[j]|, v_{l-1}[k] = sum_j |W_l[j][k]| v_l[j];

@@ -30,6 +30,13 @@
 #ifndef PF_NR
 #error "compile with -DPF_NR=<registers per lane>"
 #endif
+// PF_PREC 0 (default): 2-way split f16 operands, three products: float32-grade results.
+// PF_PREC 1: plain bf16 operands (round to nearest), ONE product, f32 accumulate; everything else (layer 1, tanh,
+//            output unit, element algebra, sums) stays float32.  The reduced-precision variant of BASELINE.json
+//            configs[4] ("fp32 vs bf16 residual tolerance study"), selected by pf_problem.mlp_dtype.
+#ifndef PF_PREC
+#define PF_PREC 0
+#endif
 #define PF_CAT2(a, b) a##b
 #define PF_CAT(a, b) PF_CAT2(a, b)
 
@@ -39,8 +46,12 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 namespace {
+
+constexpr bool BF = PF_PREC == 1;
 
 constexpr int NR = PF_NR;                 // accumulator registers per lane that carry real units
 constexpr int KS = NR > 8 ? 2 : 1;        // k-steps of 16 units
@@ -68,6 +79,11 @@ __device__ __forceinline__ h8 as_h8(unsigned a, unsigned b, unsigned c, unsigned
 // (v_fma_mixlo/hi_f16 take the f32 value and the f16 half of `hi` directly: 3 instructions per pair against 8
 // for convert-back, subtract, convert; checked by tools/mix_probe.hip)
 __device__ __forceinline__ void split_pair(float a0, float a1, unsigned& hi, unsigned& lo) {
+  if constexpr (BF) {   // plain bf16, round to nearest even (v_cvt_pk_bf16_f32); no lo part
+    hi = __builtin_bit_cast(unsigned, bf2{(__bf16)a0, (__bf16)a1});
+    lo = 0u;
+    return;
+  }
   hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a0, a1));
   unsigned l;
   asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "v"(hi));
@@ -77,6 +93,8 @@ __device__ __forceinline__ void split_pair(float a0, float a1, unsigned& hi, uns
 
 // acc += (Ahi + Alo)(Bhi + Blo) without the lo*lo term; small terms first
 __device__ __forceinline__ f32x16 mfma3(f32x16 acc, h8 ahi, h8 alo, h8 bhi, h8 blo) {
+  if constexpr (BF)
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, ahi), __builtin_bit_cast(bf8, bhi), acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
@@ -460,7 +478,7 @@ __device__ __forceinline__ void write_rows(unsigned char* region, int sp, int la
   unsigned char* p = region + sp * SP_STRIDE;
   *reinterpret_cast<u32x4*>(p + hs * 576 + e * 16) = u32x4{pk[0], pk[1], pk[2], pk[3]};
   if constexpr (!COMPACT) {
-    const unsigned k7 = pk[7] | ((bias_col && hs == 0) ? 0x68000000u : 0u);      // f16 2048.0 in the high half
+    const unsigned k7 = pk[7] | ((bias_col && hs == 0) ? (BF ? 0x45000000u : 0x68000000u) : 0u);   // 2048.0 (bf16 / f16) in the high half
     *reinterpret_cast<u32x4*>(p + C1_OFF + hs * 576 + e * 16) = u32x4{pk[4], pk[5], pk[6], k7};
   } else if constexpr (NR > 8) {
     *reinterpret_cast<u32x2*>(p + C1_OFF + 64 * (e >> 2) + 32 * hs + 8 * (e & 3)) = u32x2{pk[4], pk[5]};
@@ -586,15 +604,15 @@ __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ 
     // gradient tile of layer LL: rows d_LL through LDS; columns a_{LL-1} (LL >= 2) or the inputs (LL == 1)
     if (!(dbg & 1)) {
       write_rows(regA, 0, lane, dhi);
-      write_rows(regA, 1, lane, dlo);
+      if constexpr (!BF) write_rows(regA, 1, lane, dlo);
       if constexpr (LL >= 2) {
         write_rows(regB, 0, lane, A.hi[LL - 2], true);
-        write_rows(regB, 1, lane, A.lo[LL - 2]);
+        if constexpr (!BF) write_rows(regB, 1, lane, A.lo[LL - 2]);
       } else {
         // inputs of the element: registers 0..3 of the lower half-wave's slot (columns 0..3) of the B region
         if (h == 0) {
           *reinterpret_cast<u32x2*>(regB + lane * 16) = u32x2{xhi[0], xhi[1]};
-          *reinterpret_cast<u32x2*>(regB + SP_STRIDE + lane * 16) = u32x2{xlo[0], xlo[1]};
+          if constexpr (!BF) *reinterpret_cast<u32x2*>(regB + SP_STRIDE + lane * 16) = u32x2{xlo[0], xlo[1]};
         }
       }
       // the wave's own LDS writes are visible to its own later reads (in-order); tell the compiler only
@@ -603,8 +621,9 @@ __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       sfor<0, 2>([&](auto ks) {
         constexpr int S = ks;
-        const h8 ahi = read_operand(rd[0], S), alo = read_operand(rd[1], S);
-        const h8 bhi = read_operand(LL >= 2 ? rd[2] : rdBhi_in, S), blo = read_operand(rd[3], S);
+        const h8 ahi = read_operand(rd[0], S), bhi = read_operand(LL >= 2 ? rd[2] : rdBhi_in, S);
+        h8 alo = ahi, blo = bhi;     // (unused with plain bf16 operands)
+        if constexpr (!BF) { alo = read_operand(rd[1], S); blo = read_operand(rd[3], S); }
         T[LL - 1] = mfma3(T[LL - 1], ahi, alo, bhi, blo);
       });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -639,7 +658,8 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
   for (int i = lane; i < WAVE_SCRATCH / 16; i += 64) reinterpret_cast<uint4*>(scratch)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   // bias block: [element/4][half-wave][element%4] x (registers 12..15 as f16): KA in register 15 of the lower half-wave
-  if (threadIdx.x < 32) *reinterpret_cast<_Float16*>(cst + 960 + 64 * (threadIdx.x >> 2) + 8 * (threadIdx.x & 3) + 6) = (_Float16)PF_N32_KA;
+  if (threadIdx.x < 32)
+    *reinterpret_cast<unsigned short*>(cst + 960 + 64 * (threadIdx.x >> 2) + 8 * (threadIdx.x & 3) + 6) = BF ? 0x4500 : 0x6800;   // 2048.0
   const unsigned char* rd[4] = {operand_base(scratch, 0, lane, cst + 192), operand_base(scratch, 1, lane, cst + 192),
                                 operand_base(scratch + REGION, 0, lane, cst + 960), operand_base(scratch + REGION, 1, lane, cst + 192)};
   const unsigned char* rdBhi_in = operand_base(scratch + REGION, 0, lane, cst + 192);   // inputs image: no bias column
@@ -848,12 +868,17 @@ int launch_bwd_gea(const pf_problem* p, int which, hipStream_t s) { return launc
   pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)"); \
   return PF_ERR_UNSUPPORTED;
 
-int PF_CAT(pf_launch_net32_forward_, PF_NR)(const pf_problem* p, int which, hipStream_t s) {
+#if PF_PREC == 1
+#define PF_N32_SYM(kind) PF_CAT(PF_CAT(pf_launch_net32b_, kind), PF_NR)
+#else
+#define PF_N32_SYM(kind) PF_CAT(PF_CAT(pf_launch_net32_, kind), PF_NR)
+#endif
+int PF_N32_SYM(forward_)(const pf_problem* p, int which, hipStream_t s) {
   PF_DISPATCH(launch_fwd)
 }
-int PF_CAT(pf_launch_net32_backward_, PF_NR)(const pf_problem* p, int which, hipStream_t s) {
+int PF_N32_SYM(backward_)(const pf_problem* p, int which, hipStream_t s) {
   PF_DISPATCH(launch_bwd)
 }
-int PF_CAT(pf_launch_net32_backward_gea_, PF_NR)(const pf_problem* p, int which, hipStream_t s) {
+int PF_N32_SYM(backward_gea_)(const pf_problem* p, int which, hipStream_t s) {
   PF_DISPATCH(launch_bwd_gea)
 }

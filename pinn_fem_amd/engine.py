@@ -45,7 +45,7 @@ class HipEngine:
     def __init__(self, model, measured_disp=None, measured_dofs=None, device=None,
                  wg_mode: Optional[int] = None, n_part_blocks: Optional[int] = None,
                  host_plan: Optional[HostPlan] = None, fe_mode: Optional[int] = None,
-                 iface=None):
+                 iface=None, mlp_dtype: Optional[str] = None):
         self.lib = _capi.load()
         self.device = _require_gpu(device)
         self.stream = torch.cuda.Stream(device=self.device)
@@ -120,6 +120,15 @@ class HipEngine:
         if wg_mode == _capi.PF_WG_MFMA32 and any(sp.enabled and sp.width > _capi.PF_N32_WIDTH_MAX for sp in self.specs):
             wg_mode = _capi.PF_WG_MFMA44          # widths 31, 32: the exact-f32 4x4x1 engine (another HIP engine)
         self.wg_mode = wg_mode
+        # precision of the MLP matrix products: "f32" (split-f16 operands, float32-grade) or "bf16" (plain bf16 operands);
+        # the reduced-precision variant exists only in the MFMA32 engine
+        if mlp_dtype is None:
+            mlp_dtype = getattr(model, "_pf_mlp_dtype", None) or os.environ.get("PINNFEM_MLP_DTYPE", "f32")
+        if mlp_dtype not in ("f32", "bf16"):
+            raise ValueError(f"mlp_dtype must be 'f32' or 'bf16', got {mlp_dtype!r}")
+        if mlp_dtype == "bf16" and wg_mode != _capi.PF_WG_MFMA32:
+            raise NotImplementedError("mlp_dtype='bf16' needs the MFMA32 engine (net widths <= 30)")
+        self.mlp_dtype = mlp_dtype
         # MFMA32 engine: operand images of the enabled nets; scale of the coordinates in the f16 gradient products
         op_off, self._op_off = 0, [0, 0]
         if wg_mode == _capi.PF_WG_MFMA32:
@@ -239,6 +248,7 @@ class HipEngine:
         P.net_op = self.net_op.data_ptr() if self.wg_mode == _capi.PF_WG_MFMA32 else None
         P.op_off[0], P.op_off[1] = self._op_off
         P.coord_exp = self.coord_exp
+        P.mlp_dtype = _capi.PF_MLP_BF16 if self.mlp_dtype == "bf16" else _capi.PF_MLP_F32
         P.elem_s = self.elem_s.data_ptr() if self.elem_s is not None else None
         self._configured = True
 

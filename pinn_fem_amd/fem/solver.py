@@ -73,7 +73,8 @@ def _engine_for(model: FEMModel, measured_disp, measured_dofs) -> HipEngine:
     key = (None if measured_disp is None else np.asarray(measured_disp, dtype=float).tobytes(),
            None if measured_dofs is None else np.asarray(measured_dofs, dtype=int).tobytes(),
            model.nodes.tobytes(), model.elements.tobytes(), model.loads.tobytes(),
-           model.fixed_dofs.tobytes(), _material_signature(model))
+           model.fixed_dofs.tobytes(), _material_signature(model), getattr(model, "_pf_mlp_dtype", None),
+           getattr(model, "_pf_fe_mode", None))
     cache = getattr(model, "_pf_engine_cache", None)
     if cache is not None and cache[0] == key and (not cache[1].n_theta or cache[1].theta.still_bound()):
         return cache[1]

@@ -126,7 +126,7 @@ def _leaf_counts(run):
 
 
 @pytest.mark.parametrize("ex", ["example2", "example2-P", "example3", "example3-P", "example4",
-                                "example4-P", "example6", "example7", "example7-P"])
+                                "example4-P", "example6", "example6-P", "example7", "example7-P"])
 def test_whole_example_runs(ex, monkeypatch):
     """Whole `generic.py exampleN.json` runs (10 load increments) against the reference at seed 0:
     per-call iteration counts, converged flag, nodal displacements within 1e-5 relative
@@ -152,10 +152,13 @@ def test_whole_example_runs(ex, monkeypatch):
     ref = run["result"]
     ref_counts = _leaf_counts(run)
     assert out["converged"] == ref["converged"]
-    # the stop test compares float32 monitors with 1e-6: allow the crossing to move by a few
-    # iterations per call, and require the totals to agree within 1 %
+    # Every solve_gd call stops at EXACTLY the reference's iteration (measured on all ten examples, 1283-4942
+    # iterations per run; profiles/r02_parity_summary.json).  The stop test compares a float32 monitor with 1e-6, so a
+    # crossing that falls within round-off of the tolerance may move by one iteration: +-1 per call is the bound, and
+    # the run total must agree within 2.
     assert len(counts) == len(ref_counts)
-    assert all(abs(a - b) <= max(3, 0.02 * b) for a, b in zip(counts, ref_counts)), (counts, ref_counts)
+    assert all(abs(a - b) <= 1 for a, b in zip(counts, ref_counts)), (counts, ref_counts)
+    assert abs(sum(counts) - sum(ref_counts)) <= 2, (sum(counts), sum(ref_counts))
     assert rel_err(out["displacements"], ref["displacements"]) < 1e-5
     assert np.max(np.abs(np.array(out["reactions"]) - np.array(ref["reactions"]))) < 1e-5
     if "identified_properties" in ref:
@@ -410,7 +413,8 @@ def test_api_pinn_gd_identifies_stiffness(tmp_path):
 
 @pytest.mark.parametrize("wg", [3, 2, 1])
 @pytest.mark.parametrize("width,layers,dim", [(1, 1, 2), (4, 1, 2), (7, 2, 2), (8, 3, 2), (12, 2, 1), (16, 2, 2),
-                                                (20, 3, 2), (24, 2, 2), (28, 1, 1), (32, 2, 2), (32, 3, 1), (15, 2, 2)])
+                                                (20, 3, 2), (24, 2, 2), (28, 1, 1), (32, 2, 2), (32, 3, 1), (15, 2, 2),
+                                                (27, 2, 2), (30, 3, 1)])
 def test_net_shape_menu(width, layers, dim, wg):
     """Every padded width (4..32), 1..3 hidden layers, 1-D (input [load_factor, x]) and 2-D meshes:
     HIP vs oracle on a 150-element mesh with a different net shape for E and A."""
@@ -872,3 +876,128 @@ def test_cli_one_dimensional_list_format_json(tmp_path):
     ref2 = orc.solve(pb2, orc.SolverConfig(method="gd", n_increments=2, max_iterations=40, tolerance=1e-30,
                                            learning_rate_u=0.01, learning_rate_theta=1e-3))
     assert rel_err(np.array(out2["displacements"]).reshape(-1), ref2.displacements.reshape(-1)) < 1e-5
+
+
+# ---- reduced-precision MLP variant (BASELINE.json configs[4]: fp32 vs bf16 study) -------------------
+def test_bf16_mlp_single_step_error_bound():
+    """mlp_dtype='bf16' (plain bf16 operands of the hidden-layer and gradient products, f32 accumulate, everything else
+    float32): one loss+gradient evaluation against the float32 oracle.  bf16 carries 8 significand bits (2^-9 relative
+    rounding): documented bound 2e-3 on the properties' effect (loss), 1e-2 on the parameter gradients."""
+    rec = load_npz("step_chain300_ex4shape.npz")
+    pb = mesh_problem(rec, (20, 15, 10), (1.0, 1.0, 1.0))
+    ref = orc.loss_and_grads(pb, orc.element_geometry(pb), rec["u"], 0.7, 1.0, 100.0)
+    model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, 10), (1.0, 1.0, 1.0),
+                          theta_from(rec))
+    from pinn_fem_amd.engine import HipEngine
+    eng = HipEngine(model, rec["meas_vals"], rec["meas_dofs"], mlp_dtype="bf16")
+    losses, gu, gt = eng.loss_and_grads(torch.from_numpy(rec["u"]), 0.7, 1.0, 100.0)
+    assert abs(losses["loss_total"] - ref.loss_total) < 2e-3 * abs(ref.loss_total)
+    ref_t = np.concatenate([g.reshape(-1) for g in ref.grad_theta if g is not None])
+    err = rel_err(gt.cpu().numpy()[: ref_t.size], ref_t)
+    assert 1e-6 < err < 1e-2, err          # really the reduced-precision path, and within its bound
+    with pytest.raises(NotImplementedError):
+        HipEngine(model, rec["meas_vals"], rec["meas_dofs"], wg_mode=2, mlp_dtype="bf16")
+
+
+@pytest.mark.parametrize("ex", ["example7", "example7-P"])
+def test_bf16_mlp_hybrid_example_tolerance(ex):
+    """The hybrid examples (3 NNs) with bf16 MLP products still converge to the solver tolerance, in a comparable
+    number of iterations, to displacements within 5e-4 and identified E*A within 5e-3 of the float32 run
+    (measured: 2.6e-5 / 1.2e-4 and 7e-4 / 1.5e-3, profiles/r02_bf16_study.json)."""
+    from pinn_fem_amd.cli.generic import extract_nn_properties
+    from pinn_fem_amd.fem.solver import solve
+    run = load_run(ex)
+    theta0 = [np.array(t, dtype=np.float32) for t in run["theta0"]]
+    out = {}
+    for dt in ("f32", "bf16"):
+        parsed = product_example(ex, theta0)
+        model = parsed["model"]
+        model._pf_mlp_dtype = dt
+        md = parsed["measured_data"]
+        res = solve(model, parsed["solver_config"], md.get("values"), md.get("dofs"))
+        ident = extract_nn_properties(model)
+        ea = (np.array(ident["young"]["load_factor_variations"]["load_factor_1.0"]["at_elements"]["values"]) *
+              np.array(ident["area"]["load_factor_variations"]["load_factor_1.0"]["at_elements"]["values"]))
+        out[dt] = (res, ea)
+    r32, rbf = out["f32"][0], out["bf16"][0]
+    assert r32.converged and rbf.converged
+    assert rbf.history[-1]["residual_norm"] < 1e-3 or rbf.history[-1]["loss_total"] < parsed["solver_config"].tolerance
+    assert rel_err(rbf.displacements, r32.displacements) < 5e-4
+    assert rel_err(out["bf16"][1], out["f32"][1]) < 5e-3
+    assert abs(len(rbf.history) - len(r32.history)) <= 0.5 * len(r32.history)
+
+
+# ---- BASELINE-size checks of the product path (VERDICT r1, weak 5) ----------------------------------------------------
+def test_full_size_graph_equals_eager_bitwise():
+    """10^6 elements, ex4 shape, default element-force formulation: 40 iterations replayed as the dependency-DAG
+    hipGraph (the product path of bench.py) and the same 40 launched eagerly in stream order end in bit-identical
+    u, theta and loss history."""
+    from bench import build_model
+    from pinn_fem_amd.engine import HipEngine
+    from pinn_fem_amd.fem.solver import SolverConfig
+    outs = []
+    for use_graph in (True, False):
+        model, mv, md, _ = build_model(1_000_000, "ex4")
+        cfg = SolverConfig(max_iterations=45, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
+        eng = HipEngine(model, mv, md)
+        eng.begin(None, 0.1, cfg, want_history=True)
+        eng.iterate(40, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert eng.state().iter == 40
+        outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.history(40).copy()))
+        if use_graph:
+            assert eng.graph_creates == 1
+        del eng
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    assert np.all(np.isfinite(outs[0][2])) and outs[0][2][-1, 0] < outs[0][2][0, 0]      # and the loss went down
+
+
+def test_full_size_loss_and_grads_vs_oracle_prefix():
+    """pf_loss_and_grads at 10^6 elements (ex4 shape): f_int, grad_u and the residual-driven element adjoint on the
+    first 5000 elements equal the oracle's on that prefix (interior nodes; the prefix's last node sees one element
+    less in the oracle), and the parameter gradient is finite and reproducible run to run (fixed summation order)."""
+    n, m = 1_000_000, 5000
+    model, pb, mv, md = _chain_model(n, h=3.0 / n)
+    eng = _engine(model, mv, md, 3)
+    x = np.arange(n + 1) * (3.0 / n)
+    u = np.zeros(2 * (n + 1), dtype=np.float32)
+    u[0::2] = (0.6 * x * (1.0 + 0.05 * np.sin(7.0 * x))).astype(np.float32)
+    losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.6, 1.0, 100.0)
+    gu1, gt1 = gu.cpu().numpy().copy(), gt.cpu().numpy().copy()
+    losses2, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.6, 1.0, 100.0)
+    assert np.array_equal(gt1, gt.cpu().numpy()) and np.array_equal(gu1, gu.cpu().numpy())
+    assert losses == losses2 and np.all(np.isfinite(gt1)) and np.any(gt1 != 0)
+    # oracle on the prefix: same theta, same u; measurements of the prefix nodes; global measurement count n_meas
+    mask = np.asarray(md) < 2 * (m + 1)
+    sub_md = np.asarray(md)[mask]
+    sub = orc.Problem(nodes=pb.nodes[: m + 1], elements=pb.elements[:m], loads=pb.loads[: 2 * (m + 1)],
+                      fixed_dofs=pb.fixed_dofs[pb.fixed_dofs < 2 * (m + 1)], dimension=2,
+                      young=pb.young, area=pb.area, density=pb.density,
+                      measured_vals=np.asarray(mv)[mask], measured_dofs=sub_md)
+    ref = orc.loss_and_grads(sub, orc.element_geometry(sub), u[: 2 * (m + 1)], 0.6, 1.0, 100.0 * sub_md.size / md.size)
+    # interior dofs of the prefix (the last two nodes feel the cut)
+    k = 2 * (m - 1)
+    scale = np.max(np.abs(ref.grad_u[:k]))
+    assert np.max(np.abs(gu1[:k] - ref.grad_u[:k])) < 2e-5 * scale
+
+
+def test_config1_ex3_shape_1e5_vs_oracle():
+    """BASELINE.json configs[1]: example3 shape (E = NN, A and rho scalar) on a 10^5-element bar: 12 GD iterations of the
+    product path (plain chain inside the hipGraph below 2*10^5 elements) against the oracle, default formulation."""
+    from pinn_fem_amd.fem.solver import SolverConfig, solve_gd
+    n = 100_000
+    model, pb, mv, md = _chain_model(n, widths=(20, None, None), h=1.0)
+    cfg = SolverConfig(max_iterations=12, learning_rate_u=0.01, learning_rate_theta=1e-3, tolerance=0.0)
+    res = solve_gd(model, cfg, mv, md, target_load_factor=0.1)
+    ref = orc.solve_gd(pb, orc.SolverConfig(max_iterations=12, learning_rate_u=0.01, learning_rate_theta=1e-3,
+                                            tolerance=0.0), 0.1)
+    assert len(res.history) == len(ref.history) == 12
+    got_l = np.array([h["loss_total"] for h in res.history])
+    ref_l = np.array([h["loss_total"] for h in ref.history])
+    assert np.max(np.abs(got_l - ref_l) / np.abs(ref_l)) < 2e-5
+    assert rel_err(res.displacements, ref.displacements) < 2e-5
+    th = np.concatenate([t.reshape(-1) for t in pb.theta_list()])
+    got_th = np.concatenate([v.reshape(-1) for v in res.nn_parameters.values()])
+    assert rel_err(got_th, th) < 2e-5

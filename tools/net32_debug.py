@@ -11,7 +11,7 @@ workload = sys.argv[2] if len(sys.argv) > 2 else "ex4"
 res = {}
 for wg in (2, 3):
     model, mv, md, widths = build_model(n, workload)
-    eng = HipEngine(model, mv, md, wg_mode=wg)
+    eng = HipEngine(model, mv, md, wg_mode=wg, mlp_dtype=(os.environ.get("DBG_DTYPE", "f32") if wg == 3 else None))
     eng.eval_properties(0.1)
     torch.cuda.synchronize()
     E = eng.prop_e[:n].cpu().numpy().copy(); A = eng.prop_a[:n].cpu().numpy().copy()
