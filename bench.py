@@ -60,14 +60,24 @@ def build_model(n_elems: int, workload: str, seed: int = 0, x0: float = 0.0, mes
     return model, mv, md, widths
 
 
-def cpu_baseline(workload: str, n_sample: int, iters: int):
-    """The oracle (numpy restatement of the reference algorithm) timed on the host cores on a bounded
-    sample of the same workload: n_sample elements x iters GD iterations."""
+def _cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
+
+
+def _oracle_problem(orc, n, workload):
     import torch
-    from oracle import pinn_oracle as orc
     from pinn_fem_amd.nets import SimpleNN
     from pinn_fem_amd.plan import chain_mesh
-    nodes, elements, loads, fixed, mv, md = chain_mesh(n_sample, 1.0)
+    nodes, elements, loads, fixed, mv, md = chain_mesh(n, 1.0)
     torch.manual_seed(0)
     widths = {"ex4": (20, 15, 10), "ex3": (20, None, None)}[workload]
     props = []
@@ -76,24 +86,56 @@ def cpu_baseline(workload: str, n_sample: int, iters: int):
             props.append(1.0)
         else:
             props.append(orc.NetParams([p.detach().numpy().copy() for p in SimpleNN(2, w, 3).parameters()]))
-    pb = orc.Problem(nodes=nodes, elements=elements, loads=loads, fixed_dofs=fixed, dimension=2,
-                     young=props[0], area=props[1], density=props[2], measured_vals=mv, measured_dofs=md)
-    cfg = orc.SolverConfig(max_iterations=iters, learning_rate_u=0.01,
-                           learning_rate_theta=5e-4 if workload == "ex4" else 1e-3, tolerance=0.0)
-    geo = orc.element_geometry(pb)
-    orc.solve_gd(pb, orc.SolverConfig(max_iterations=1, tolerance=0.0), 0.1, geo=geo)  # touch pages
-    t0 = time.perf_counter()
-    orc.solve_gd(pb, cfg, 0.1, geo=geo)
-    dt = time.perf_counter() - t0
+    return orc.Problem(nodes=nodes, elements=elements, loads=loads, fixed_dofs=fixed, dimension=2,
+                       young=props[0], area=props[1], density=props[2], measured_vals=mv, measured_dofs=md)
+
+
+def cpu_baseline(workload: str, n_sample: int, iters: int, threads: int):
+    """The oracle (numpy restatement of the reference algorithm, kind "port") timed on the host cores on bounded
+    samples of the same workload:
+      (R) reference-ORDER mode, one element at a time like assemble_system_torch's Python loop, N = 3 / 300 / 1000
+          (beside BASELINE.md's import-measured reference: 676 / 474 / 430 element-evals/s on 8 cores);
+      (V) vectorised mode (batched MLP + matrix-free assembly), N = 10^5 and the headline sample size.
+    Thread pools (BLAS) are pinned to `threads`; numpy's element-wise work is single-threaded either way."""
+    from oracle import pinn_oracle as orc
     try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=threads)
     except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": n_sample * iters / dt, "unit": "element-evals/s", "cores": int(threads),
-            "kind": "port",
-            "sample": f"oracle/pinn_oracle.py solve_gd, {n_sample} elements x {iters} GD iterations, "
-                      f"{workload} shape, {dt:.1f} s wall, host has {os.cpu_count()} cpus"}
+        limiter = None
+    lr_t = 5e-4 if workload == "ex4" else 1e-3
+    model_name, ncpu = _cpu_info()
+    rows = []
+    ref_rows = {3: 676.0, 300: 474.0, 1000: 430.0}            # BASELINE.md section 2 (reference imported, 8 cores)
+    for n, it in ((3, 400), (300, 10), (1000, 4)):
+        pb = _oracle_problem(orc, n, workload)
+        cfg = orc.SolverConfig(learning_rate_u=0.01, learning_rate_theta=lr_t, tolerance=0.0)
+        orc.gd_iterations_loop(pb, cfg, 0.1, 1)
+        t0 = time.perf_counter()
+        orc.gd_iterations_loop(pb, cfg, 0.1, it)
+        dt = time.perf_counter() - t0
+        rows.append({"mode": "R (reference order, per-element loop)", "n_elems": n, "iterations": it,
+                     "value": n * it / dt, "unit": "element-evals/s", "wall_s": dt,
+                     "reference_measured_BASELINE_md": ref_rows[n]})
+    head = None
+    for n, it in ((100_000, max(iters, 10)), (n_sample, iters)):
+        pb = _oracle_problem(orc, n, workload)
+        cfg = orc.SolverConfig(max_iterations=it, learning_rate_u=0.01, learning_rate_theta=lr_t, tolerance=0.0)
+        geo = orc.element_geometry(pb)
+        orc.solve_gd(pb, orc.SolverConfig(max_iterations=1, tolerance=0.0), 0.1, geo=geo)  # touch pages
+        t0 = time.perf_counter()
+        orc.solve_gd(pb, cfg, 0.1, geo=geo)
+        dt = time.perf_counter() - t0
+        head = {"mode": "V (vectorised)", "n_elems": n, "iterations": it, "value": n * it / dt,
+                "unit": "element-evals/s", "wall_s": dt}
+        rows.append(head)
+    if limiter is not None:
+        limiter.restore_original_limits()
+    return {"value": head["value"], "unit": "element-evals/s", "cores": int(threads), "kind": "port",
+            "sample": f"oracle/pinn_oracle.py solve_gd (vectorised), {head['n_elems']} elements x {head['iterations']} GD "
+                      f"iterations, {workload} shape, {head['wall_s']:.1f} s wall; thread pools pinned to {threads} "
+                      f"of {ncpu} logical CPUs ({model_name})",
+            "cpu_model": model_name, "host_cpus": ncpu, "rows": rows}
 
 
 def side_config(workload, n_elems, dev, steps, mesh="chain"):
@@ -140,8 +182,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--elems", type=int, default=1_000_000, help="elements per GPU")
     ap.add_argument("--workload", default="ex4", choices=["ex4", "ex3"])
-    ap.add_argument("--cpu-sample", type=int, default=200_000)
-    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-iters", type=int, default=5)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="thread-pool size of the CPU baseline (0: min(64, cpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] measurement")
     args = ap.parse_args()
@@ -293,7 +336,8 @@ def main():
                            "ex4 shape, Warren girder, 1e6 elements, 1 GPU": side_config("ex4", 1_000_000, dev, args.steps,
                                                                                          mesh="warren")}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.cpu_iters)
+            threads = args.cpu_threads or min(64, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.cpu_iters, threads)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

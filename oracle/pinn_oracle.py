@@ -651,3 +651,166 @@ def solve(pb: Problem, config: Optional[SolverConfig] = None,
         if not result.converged:                                       # :1161-1165
             break
     return result
+
+
+# ----------------------------------------------------------------------------------
+# (R) reference-ORDER mode: one element at a time, like assemble_system_torch's Python loop
+# (fem/nn_assembly.py:181-229): batch-1 MLP call per property, 4x4 (2x2) element matrix, 16 (4) indexed
+# `+=` into the dense K and 4 (2) into f_int, then the per-element chain rule that autograd applies
+# in reverse element order.  Same numbers as the vectorised functions above (tests/test_oracle_golden.py),
+# at the cost class of the reference (10^2..10^3 element-evals/s): bench.py's cpu_baseline rows "(R)".
+# ----------------------------------------------------------------------------------
+def loss_and_grads_loop(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
+                        alpha_physics: float = 1.0, alpha_data: float = 100.0) -> StepOut:
+    u = u.astype(f32)
+    ndof, nelm, nd = pb.ndof, geo.dofs.shape[0], geo.dofs.shape[1]
+    free, fixed = free_and_fixed_dofs(ndof, pb.fixed_dofs)
+    k_global = np.zeros((ndof, ndof), dtype=f32)            # nn_assembly.py:128 (never read by the loss)
+    f_int = np.zeros(ndof, dtype=f32)
+    x_all = nn_inputs(geo, lam)
+    ctx = []
+    for e in range(nelm):                                   # :181
+        x = x_all[e:e + 1]
+        e_val, e_ctx = property_forward(pb.young, x)        # :207 (batch of one)
+        a_val, a_ctx = property_forward(pb.area, x)
+        s = (e_val[0] * a_val[0]) / geo.l0[e]               # :74
+        ke = (f32(s) * geo.pattern[e]).astype(f32)
+        dofs = geo.dofs[e]
+        ue = u[dofs]
+        fe = np.zeros(nd, dtype=f32)
+        for b in range(nd):                                 # ke @ u_e, b ascending (:96-100)
+            fe = (fe + ke[:, b] * ue[b]).astype(f32)
+        for a in range(nd):                                 # :226-229
+            f_int[dofs[a]] = f32(f_int[dofs[a]] + fe[a])
+            for b in range(nd):
+                k_global[dofs[a], dofs[b]] = f32(k_global[dofs[a], dofs[b]] + ke[a, b])
+        ctx.append((e_val[0], a_val[0], e_ctx, a_ctx, f32(s)))
+    f_ext = pb.loads.astype(f32)
+    r = (f_int[free] - f32(lam) * f_ext[free]).astype(f32)
+    loss_p = f32(0.5) * np.sum(r * r, dtype=f32)
+    has_meas = pb.measured_vals is not None and pb.measured_dofs is not None
+    use_data = has_meas and alpha_data > 0 and len(pb.measured_vals) > 0
+    if use_data:
+        mv, md = pb.measured_vals.astype(f32), pb.measured_dofs.astype(int)
+        d = (mv - u[md]).astype(f32)
+        loss_d = np.mean(d * d, dtype=f32)
+        loss = f32(alpha_physics) * loss_p + f32(alpha_data) * loss_d
+    else:
+        loss_d = f32(0.0)
+        loss = f32(alpha_physics) * loss_p
+    rn = f32(np.sqrt(np.sum(r * r, dtype=f32)))
+    g_f = np.zeros(ndof, dtype=f32)
+    g_f[free] = (f32(alpha_physics) * r).astype(f32)
+    grad_u = np.zeros(ndof, dtype=f32)
+    if use_data:
+        np.add.at(grad_u, md, (-(f32(alpha_data) / f32(len(mv))) * (f32(2.0) * d)).astype(f32))
+    nets = [p for p in (pb.young, pb.area) if isinstance(p, NetParams)]
+    acc: List[List[np.ndarray]] = [[np.zeros_like(t, dtype=f32) for t in p.tensors] for p in nets]
+    for e in range(nelm):
+        e_val, a_val, e_ctx, a_ctx, s = ctx[e]
+        dofs = geo.dofs[e]
+        g_fe, ue = g_f[dofs], u[dofs]
+        ke = (s * geo.pattern[e]).astype(f32)
+        for b in range(nd):                                 # grad wrt u_e: ke^T g_fe
+            grad_u[dofs[b]] = f32(grad_u[dofs[b]] + np.sum(ke[:, b] * g_fe, dtype=f32))
+        pu = np.zeros(nd, dtype=f32)
+        for b in range(nd):
+            pu = (pu + geo.pattern[e][:, b] * ue[b]).astype(f32)
+        g_ea = f32(np.sum(g_fe * pu, dtype=f32) / geo.l0[e])
+        k = 0
+        for prop, c, other in ((pb.young, e_ctx, a_val), (pb.area, a_ctx, e_val)):
+            if isinstance(prop, NetParams):
+                z, acts = c
+                g_out = np.array([g_ea * other * f32(prop.scale)], dtype=f32)
+                g_z = (g_out * softplus_grad(z)).astype(f32) if prop.enforce_positive else g_out
+                for t, g in enumerate(mlp_backward(prop, acts, g_z)):
+                    acc[k][t] = (acc[k][t] + g.reshape(acc[k][t].shape)).astype(f32)
+                k += 1
+    grad_theta: List[Optional[np.ndarray]] = [g for lst in acc for g in lst]
+    if isinstance(pb.density, NetParams):
+        grad_theta.extend([None] * len(pb.density.tensors))
+    s_all = np.array([c[4] for c in ctx], dtype=f32)
+    return StepOut(f_int=f_int, r=r, loss_physics=float(loss_p), loss_data=float(loss_d), loss_total=float(loss),
+                   residual_norm=float(rn), grad_u=grad_u, grad_theta=grad_theta, stiffness=s_all,
+                   young=np.array([c[0] for c in ctx], dtype=f32), area=np.array([c[1] for c in ctx], dtype=f32))
+
+
+def gd_iterations_loop(pb: Problem, config: SolverConfig, lam: float, n_iter: int) -> np.ndarray:
+    """n_iter iterations of solve_gd's loop body (solver.py:254-298) in reference-order mode; returns u."""
+    geo = element_geometry(pb)
+    theta = pb.theta_list()
+    u = np.zeros(pb.ndof, dtype=f32)
+    free, fixed = free_and_fixed_dofs(pb.ndof, pb.fixed_dofs)
+    opt_u = AdamState(lr=config.learning_rate_u)
+    opt_t = AdamState(lr=config.learning_rate_theta) if theta else None
+    for _ in range(n_iter):
+        st = loss_and_grads_loop(pb, geo, u, lam, config.alpha_physics, config.alpha_data)
+        opt_u.update([u], [st.grad_u])
+        if opt_t is not None:
+            opt_t.update(theta, st.grad_theta)
+        u[fixed] = f32(0.0)
+    return u
+
+
+# ----------------------------------------------------------------------------------
+# pinn_inverse_problem_gd: the callee FEM/python/api_pinn_gradient_descent.py:19 imports but the reference
+# never defines (ImportError at import; SURVEY.md section 0.1).  PARITY UNPINNED against the reference: there is no
+# reference behaviour.  This restates the PRODUCT's definition (pinn_fem_amd/fem/nn_solver_gd.py), which takes the
+# contract from the wrapper's call site (api_pinn_gradient_descent.py:102-121, 154-176) and the arithmetic from the
+# nearest existing code, the legacy solver fem/nn_solver_gd.py:105-125:
+#     loss = alpha * mean(r_free^2) + beta * mean((u_meas - u[md])^2),  r = (E A / E0 A0) K_1 u - F / (E0 A0),
+#     E = E0 exp(p_E), A = A0 exp(p_A);  torch.optim.Adam, two parameter groups (u: lr * max|u_meas|, p: lr).
+# ----------------------------------------------------------------------------------
+def pinn_inverse_problem_gd(nodes, elements, f_ext, fixed_dofs, young_init, area_init, u_measured, measured_dofs,
+                            n_iterations=500, learning_rate=1e-3, alpha=1.0, beta=100.0,
+                            young_bounds=None, area_bounds=None) -> Dict:
+    nodes = np.asarray(nodes, dtype=float)
+    elements = np.asarray(elements, dtype=int)
+    f_ext = np.asarray(f_ext, dtype=float).reshape(-1)
+    pb = Problem(nodes=nodes, elements=elements, loads=f_ext, fixed_dofs=np.asarray(fixed_dofs, dtype=int),
+                 dimension=2, young=1.0, area=1.0, density=1.0)
+    geo = element_geometry(pb)
+    ndof = pb.ndof
+    free, fixed = free_and_fixed_dofs(ndof, pb.fixed_dofs)
+    md = np.asarray(measured_dofs, dtype=int)
+    um = np.asarray(u_measured, dtype=f32)
+    fx = f_ext.astype(f32)
+    ea0 = float(young_init) * float(area_init)
+    s1 = (f32(1.0) / geo.l0).astype(f32)                    # unit stiffness: E = A = 1
+    u = np.zeros(ndof, dtype=f32)
+    p = np.zeros(2, dtype=f32)
+    u_scale = float(np.max(np.abs(um))) if um.size else 1.0
+    opt_u = AdamState(lr=learning_rate * max(u_scale, 1e-30))
+    opt_p = AdamState(lr=learning_rate)
+    lo = hi = None
+    if young_bounds is not None and area_bounds is not None:
+        lo = np.array([np.log(young_bounds[0] / young_init), np.log(area_bounds[0] / area_init)], dtype=f32)
+        hi = np.array([np.log(young_bounds[1] / young_init), np.log(area_bounds[1] / area_init)], dtype=f32)
+    history = []
+    nf, nm = f32(len(free)), f32(max(len(md), 1))
+    for it in range(int(n_iterations)):
+        k1u = internal_force(geo, s1, u, ndof)
+        c = f32(np.exp(f32(p[0] + p[1]), dtype=f32))
+        r = (c * k1u[free] - fx[free] / f32(ea0)).astype(f32)
+        loss_p = np.mean(r * r, dtype=f32)
+        d = (um - u[md]).astype(f32)
+        loss_d = np.mean(d * d, dtype=f32) if len(md) else f32(0.0)
+        loss = f32(alpha) * loss_p + f32(beta) * loss_d
+        g_r = (f32(alpha) * f32(2.0) * r / nf).astype(f32)
+        g_f = np.zeros(ndof, dtype=f32)
+        g_f[free] = (c * g_r).astype(f32)
+        grad_u = np.zeros(ndof, dtype=f32)
+        np.add.at(grad_u, geo.dofs.reshape(-1), ke_times(geo, s1, g_f[geo.dofs]).reshape(-1))
+        if len(md):
+            np.add.at(grad_u, md, (-(f32(beta) * f32(2.0) / nm) * d).astype(f32))
+        g_c = np.sum(g_r * k1u[free], dtype=f32) * c        # d loss / d (p_E + p_A)
+        opt_u.update([u], [grad_u])
+        opt_p.update([p], [np.array([g_c, g_c], dtype=f32)])
+        u[fixed] = f32(0.0)
+        if lo is not None:
+            np.clip(p, lo, hi, out=p)
+        history.append({"iteration": it + 1, "loss_total": float(loss), "loss_physics": float(loss_p),
+                        "loss_data": float(loss_d), "young": float(young_init * np.exp(float(p[0]))),
+                        "area": float(area_init * np.exp(float(p[1])))})
+    return {"u_final": u.astype(np.float64), "young_final": float(young_init * np.exp(float(p[0]))),
+            "area_final": float(area_init * np.exp(float(p[1]))), "history": history}

@@ -55,8 +55,11 @@ def pinn_inverse_problem_gd(nodes, elements, f_ext, fixed_dofs, young_init: floa
                           dtype=torch.float32, device=dev)
         hi = torch.tensor([np.log(young_bounds[1] / young_init), np.log(area_bounds[1] / area_init)],
                           dtype=torch.float32, device=dev)
-    history: List[Dict[str, float]] = []
-    for it in range(int(n_iterations)):
+    # No host synchronisation inside the loop: the monitors of every iteration go to a device table that is read
+    # once at the end (the loop is then bound by launch rate, not by a .item() round trip per quantity).
+    n_it = int(n_iterations)
+    table = torch.zeros((max(n_it, 1), 5), dtype=torch.float32, device=dev)   # loss, loss_p, loss_d, p_E, p_A
+    for it in range(n_it):
         opt.zero_grad(set_to_none=True)
         k1u = internal_force(eng, u, 1.0)                         # HIP: K_1 u, differentiable in u
         r = torch.exp(p[0] + p[1]) * k1u[free_t] - fx[free_t] / ea0
@@ -69,10 +72,13 @@ def pinn_inverse_problem_gd(nodes, elements, f_ext, fixed_dofs, young_init: floa
             u[fixed_t] = 0.0
             if lo is not None:
                 p.copy_(torch.minimum(torch.maximum(p, lo), hi))
-        pe, pa = (float(x) for x in p.detach().cpu())
-        history.append({"iteration": it + 1, "loss_total": float(loss.item()),
-                        "loss_physics": float(loss_p.item()), "loss_data": float(loss_d.item()),
-                        "young": float(young_init * np.exp(pe)), "area": float(area_init * np.exp(pa))})
+            table[it, 0], table[it, 1], table[it, 2] = loss.detach(), loss_p.detach(), loss_d.detach()
+            table[it, 3:5] = p.detach()
+    rows = table.cpu().numpy().astype(np.float64)
+    history: List[Dict[str, float]] = [
+        {"iteration": it + 1, "loss_total": float(rows[it, 0]), "loss_physics": float(rows[it, 1]),
+         "loss_data": float(rows[it, 2]), "young": float(young_init * np.exp(rows[it, 3])),
+         "area": float(area_init * np.exp(rows[it, 4]))} for it in range(n_it)]
     pe, pa = (float(x) for x in p.detach().cpu())
     return {"u_final": u.detach().cpu().numpy().astype(np.float64),
             "young_final": float(young_init * np.exp(pe)), "area_final": float(area_init * np.exp(pa)),

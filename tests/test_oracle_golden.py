@@ -211,3 +211,42 @@ def test_oracle_nr_and_scalar_hybrid_runs(ex):
     if "iteration" in rlast:          # hybrid with a GD phase: unified iteration count (solver.py:676-684)
         assert abs(last["iteration"] - rlast["iteration"]) <= 3
         assert abs(len(res.history) - len(ref["history"])) <= 3
+
+
+def test_reference_order_loop_mode_equals_vectorised():
+    """(R) mode: the per-element restatement (one element at a time, batch-1 MLP calls, indexed += into a dense K,
+    per-element chain rule) gives the vectorised oracle's numbers; bench.py times it as the reference-order CPU row."""
+    from helpers import load_npz, mesh_problem
+    # (the 300-element chain amplifies the 1e-7 difference between batch-1 and batched matrix products by the
+    # float32 cancellation of the reference's 4-term dot: its tolerances are 30x wider)
+    for name, widths, scales, k in (("step_warren_EA.npz", (20, 15, None), (2.0, 0.5, 1.0), 1.0),
+                                    ("step_chain300_ex4shape.npz", (20, 15, 10), (1.0, 1.0, 1.0), 30.0)):
+        rec = load_npz(name)
+        pb = mesh_problem(rec, widths, scales)
+        geo = orc.element_geometry(pb)
+        a = orc.loss_and_grads(pb, geo, rec["u"], 0.7, 1.0, 100.0)
+        b = orc.loss_and_grads_loop(pb, geo, rec["u"], 0.7, 1.0, 100.0)
+        assert abs(a.loss_total - b.loss_total) <= 1e-6 * k * abs(a.loss_total)
+        assert np.max(np.abs(a.f_int - b.f_int)) <= 1e-6 * k * np.max(np.abs(a.f_int))
+        assert np.max(np.abs(a.grad_u - b.grad_u)) <= 2e-6 * k * np.max(np.abs(a.grad_u))
+        for ga, gb in zip(a.grad_theta, b.grad_theta):
+            assert (ga is None) == (gb is None)
+            if ga is not None:
+                assert np.max(np.abs(ga.reshape(gb.shape) - gb)) <= 5e-6 * k * max(np.max(np.abs(ga)), 1e-30)
+
+
+def test_inverse_gd_oracle_identifies_axial_stiffness():
+    """oracle.pinn_inverse_problem_gd (restatement of the PRODUCT's definition; parity unpinned against the reference,
+    whose callee does not exist): a 3-element bar with E*A twice the initial guess is identified to 1e-4."""
+    nodes = np.stack([np.arange(4.0), np.zeros(4)], axis=1)
+    el = np.array([[0, 1], [1, 2], [2, 3]])
+    f = np.zeros(8)
+    f[6] = 1000.0
+    e0, a0 = 1e6, 1e-3
+    ea = 2 * e0 * a0
+    um = np.array([1000.0 / ea * k for k in (1, 2, 3)])
+    out = orc.pinn_inverse_problem_gd(nodes, el, f, [0, 1, 3, 5, 7], e0, a0, um, [2, 4, 6], n_iterations=3000,
+                                      learning_rate=5e-3)
+    assert abs(out["young_final"] * out["area_final"] / ea - 1.0) < 1e-4
+    assert out["history"][-1]["loss_total"] < 1e-6 * out["history"][0]["loss_total"]
+    assert np.max(np.abs(out["u_final"][[2, 4, 6]] - um)) < 1e-5
