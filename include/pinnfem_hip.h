@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 3
+#define PF_ABI_VERSION 4
 
 /* error codes */
 #define PF_OK 0
@@ -143,15 +143,18 @@ typedef struct pf_problem {
   const int32_t* pad_index;/* dev [n_theta_active] torch-layout index -> padded-image index */
   float n_meas_f;          /* (float)mesh.n_meas; multi-GPU: the GLOBAL count */
   int32_t fe_mode;         /* PF_FE_* : how fe = ke @ u_e is evaluated */
-  /* multi-GPU shard interface (NULL / 0 on one GPU): dofs of nodes shared with other ranks */
+  /* multi-GPU shard interface (NULL / 0 on one GPU): the dofs of this rank's INTERFACE nodes = nodes shared with
+   * other ranks plus the other nodes of the elements around them (ghost nodes here, or boundary-near nodes of which
+   * another rank holds a ghost copy).  Their grad_u is completed by the iteration's all-reduce. */
   const int32_t* shared_dofs; /* dev [n_shared] local dof index */
   const int32_t* shared_slot; /* dev [n_shared] position in the global interface vector */
   int32_t n_shared;
   int32_t n_iface;         /* length of the global interface vector */
-  /* local elements incident to a shared node, ascending (evaluated ahead of the rest so that the
-   * interface all-reduce overlaps the full forward pass); NULL / 0 on one GPU */
-  const int32_t* iface_elems;
-  int32_t n_iface_elems;
+  /* multi-GPU: the local mesh = this rank's OWN elements plus the ghost elements (other ranks' elements incident to a
+   * shared node), sorted by global id, so the own elements are the local range [own_lo, own_hi); 0, 0 on one GPU.
+   * Gradients (MLP backward, grad_u) are taken over the own elements only. */
+  int32_t own_lo, own_hi;
+  int32_t _pad3;
   /* != 0: prop_e and prop_a hold 2*n_elems floats; the iteration graph then alternates between the two
    * halves, so the forwards of iteration t+1 need not wait for the last reader of iteration t's properties */
   int32_t prop_double;
@@ -246,66 +249,36 @@ int pf_gd_iterations_timed(const pf_problem* p, int n_iter, void* stream, float*
  * Requires p->grad_u != NULL.  Leaves loss terms in p->state, gradients in grad_u/grad_theta. */
 int pf_loss_and_grads(const pf_problem* p, void* stream);
 
-/* ---- multi-GPU shard interface (elements sharded across ranks) ------------------
- * No reference analogue: the reference is single-process.  A shard assembles only its own elements;
- * nodes shared with another shard get their f_int / grad_u completed by an all-reduce (RCCL) of a
- * short interface vector that the host issues between these calls. */
-/* iface[slot] = vec[shared_dof] for this rank's shared dofs, other slots 0.  iface dev [n_iface] */
-int pf_iface_pack(const pf_problem* p, const float* vec, float* iface, void* stream);
-/* after the all-reduce of f_int on the interface: residual, dL/df_int and loss sums of the shared
- * dofs (owner rank only for the sums); writes p->g_f and the extra partial slot. */
-int pf_iface_fix_residual(const pf_problem* p, const float* iface, void* stream);
-/* local sums of the block partials: sums3 (dev, 3 floats) = sum r^2, sum d^2, sum u_free^2 */
-int pf_local_sums(const pf_problem* p, float* sums3, void* stream);
-/* grad_u[shared_dof] = iface[slot] (the all-reduced interface gradient) */
-int pf_iface_unpack(const pf_problem* p, const float* iface, float* vec, void* stream);
-/* optimizer_u.step() + BC clamp + sum u_free^2 partials from p->grad_u (solver.py:292,297-298,304) */
-int pf_adam_u(const pf_problem* p, void* stream);
-/* optimizer_theta.step() from p->grad_theta (already reduced over ranks) + padded image refresh */
-int pf_adam_theta(const pf_problem* p, void* stream);
-/* monitors/history/stop test from globally reduced sums: sums_r2d2 (dev, 2 floats: sum r^2, sum d^2)
- * and sum_u2 (dev, 1 float) */
-int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* sum_u2, void* stream);
-
-/* One sharded iteration = five phases in stream order around TWO small all-reduces the host issues:
- *   A  pf_shard_iface_forward   the nets on the interface elements only (same arithmetic as the full
- *                               kernels, bit for bit) and the partial f_int of the shared dofs
- *                               -> iface1[slot]                                      => all-reduce(buf1)
- *   B  pf_shard_forward         the nets on all elements
- *   C  pf_shard_backward        node_residual with the reduced f_int on shared dofs (sums by the owner),
- *                               nets backward, theta reduction into p->grad_theta (which the host points
- *                               inside buf2), partial grad_u of the shared dofs, local sums
- *                               -> buf2 = [iface grad_u | grad_theta | r2, d2, 0]
- *   D  pf_shard_update_interior grad_u + Adam(u) + clamp of every dof that is NOT shared  => all-reduce(buf2)
- *   E  pf_shard_update_shared   Adam(theta) from the reduced gradient, Adam(u) of the shared dofs from
- *                               buf2, sums3 = [0, 0, local sum u_free^2 of owned dofs]
- * pf_finalize_from() of iteration t runs after all-reduce 1 of iteration t+1, which carries sums3 (before C).
- * A comes first so that the first exchange needs only a one-block kernel, not the full forward pass.
- * Requires p->n_iface_elems <= PF_MAX_IFACE_ELEMS (else phase A returns PF_ERR_UNSUPPORTED and the host
- * runs B first and gathers the shared dofs with pf_internal_force + pf_iface_pack). */
-#define PF_MAX_IFACE_ELEMS 2048
-int pf_shard_iface_forward(const pf_problem* p, float* iface1, void* stream);
+/* ---- multi-GPU (elements sharded across ranks) ----------------------------------------------------
+ * No reference analogue: the reference is single-process.  A rank holds its own elements plus one ring of GHOST
+ * elements (every element of another rank that touches a node shared with this rank), so the internal force of every
+ * node of an own element is complete without communication.  One sharded iteration is
+ *   pf_shard_forward          the nets on all local elements (own + ghost)
+ *   pf_shard_backward         residual + losses, nets backward over the OWN elements, theta reduction into
+ *                             p->grad_theta (which the host points inside buf), this rank's share of grad_u on the
+ *                             interface dofs, local sums
+ *                             -> buf = [iface grad_u (n_iface) | grad_theta (n_theta_active) | r2, d2, u2 of the previous iteration]
+ *   pf_shard_update_interior  grad_u + Adam(u) + clamp of every dof that is NOT an interface dof
+ *                                                                                      => ONE all-reduce(buf), issued by the host
+ *   pf_shard_update_shared    Adam(theta) from the reduced gradient, Adam(u) of the interface dofs (every rank that
+ *                             holds a copy applies the same step), u2_local[0] = this rank's sum u_free^2 over its
+ *                             dofs, then the bookkeeping of the iteration (monitors, history row, stop test) from the
+ *                             reduced sums; the u-norm, a monitor only, lags one iteration behind
+ * and after the last iteration of a chunk: all-reduce(u2_local) => pf_shard_flush completes the last history row. */
 int pf_shard_forward(const pf_problem* p, void* stream);
-int pf_shard_backward(const pf_problem* p, const float* iface1, float* buf2, void* stream);
+int pf_shard_backward(const pf_problem* p, float* buf, const float* u2_local, void* stream);
 int pf_shard_update_interior(const pf_problem* p, void* stream);
-int pf_shard_update_shared(const pf_problem* p, const float* buf2, float* sums3, void* stream);
-/* Phases B, C and D (+ pf_finalize_from of the previous iteration when with_finalize) as ONE hipGraph
- * with the single-GPU schedule's branches: bookkeeping beside the forwards, D beside backward #2 and the
- * theta reduction.  buf1 = dev [3 + n_iface] (sums3 | iface1), buf2 as above; the record and the pointers
- * are baked in.  Handle for pf_graph_launch / pf_graph_destroy. */
-int pf_shard_graph_create(const pf_problem* p, float* buf1, float* buf2, int with_finalize, void* stream,
-                          void** graph_out);
+int pf_shard_update_shared(const pf_problem* p, const float* buf, float* u2_local, void* stream);
+int pf_shard_flush(const pf_problem* p, const float* u2_reduced, void* stream);
 
-/* The same iteration driven from C with an own RCCL communicator (pf_comm.hip): the product path on real
- * multi-GPU runs.  librccl is dlopen'ed from `librccl_path` (the library PyTorch loaded; NULL/"" =
- * "librccl.so"); there is no link-time dependency.
+/* The same iteration driven from C with an own RCCL communicator (pf_comm.hip): the product path on real multi-GPU
+ * runs.  librccl is dlopen'ed from `librccl_path` (the library PyTorch loaded; NULL/"" = "librccl.so"); there is no
+ * link-time dependency.
  *   rank 0: pf_comm_unique_id -> 128 bytes, broadcast by the host (torch.distributed) -> every rank:
  *   pf_comm_create (collective, like ncclCommInitRank).
- * pf_shard_iterations enqueues n_iter iterations on `stream` — A, ncclAllReduce(buf1), the graph of
- * pf_shard_graph_create (graph_first for the first iteration of the call, graph_next after it; both NULL:
- * the phases one by one), ncclAllReduce(buf2), E — plus the closing flush + bookkeeping, and returns
- * without waiting for the device.  buf1 = dev [3 + n_iface], buf2 = dev [n_iface + n_theta_active + 3], and
- * p->grad_theta must point at buf2 + n_iface. */
+ * pf_shard_iterations enqueues n_iter iterations on `stream` (the four calls above around ONE ncclAllReduce each) plus
+ * the closing flush, and returns without waiting for the device.  buf = dev [n_iface + n_theta_active + 3],
+ * u2_local = dev [1], and p->grad_theta must point at buf + n_iface. */
 #define PF_COMM_ID_BYTES 128
 int pf_comm_unique_id(const char* librccl_path, void* id_out);
 int pf_comm_create(const char* librccl_path, const void* id, int rank, int world, void** comm_out);
@@ -314,8 +287,7 @@ int pf_comm_destroy(void* comm);
 int pf_comm_info(void* comm, int* rank_out, int* nranks_out);
 /* sum over ranks of buf[0..n), in place, on `stream` (the collective pf_shard_iterations issues, on its own) */
 int pf_comm_all_reduce(void* comm, float* buf, int n, void* stream);
-int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf1, float* buf2,
-                        void* graph_first, void* graph_next, void* stream);
+int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf, float* u2_local, void* stream);
 
 /* ---- classical Newton-Raphson support (pf_pcg.hip) ---------------------------
  * The reference's solve_nr (FEM/python/fem/solver.py:408-512) solves K_ff du_f = rhs_f with

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpinnfem_hip.so")
 
-PF_ABI_VERSION = 3
+PF_ABI_VERSION = 4
 PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_DOF_FIXED, PF_DOF_MEASURED, PF_DOF_SHARED, PF_DOF_GHOST = 1, 2, 4, 8
 PF_WG_SHUFFLE, PF_WG_MFMA, PF_WG_MFMA44, PF_WG_MFMA32 = 0, 1, 2, 3
@@ -20,7 +20,6 @@ PF_MLP_F32, PF_MLP_BF16 = 0, 1
 PF_FE_REFERENCE, PF_FE_DELTA = 0, 1
 PF_HIST_COLS = 6
 PF_MAX_BLOCKS = 1024
-PF_MAX_IFACE_ELEMS = 2048
 PF_COMM_ID_BYTES = 128
 PF_MAX_NODE_BLOCKS = 4096
 PF_NODE_SLOTS = PF_MAX_NODE_BLOCKS + 8
@@ -82,7 +81,7 @@ class PfProblem(C.Structure):
         ("n_meas_f", C.c_float), ("fe_mode", C.c_int32),
         ("shared_dofs", C.c_void_p), ("shared_slot", C.c_void_p),
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
-        ("iface_elems", C.c_void_p), ("n_iface_elems", C.c_int32), ("prop_double", C.c_int32),
+        ("own_lo", C.c_int32), ("own_hi", C.c_int32), ("_pad3", C.c_int32), ("prop_double", C.c_int32),
         ("net_op", C.c_void_p), ("op_off", C.c_int32 * 2), ("coord_exp", C.c_int32), ("mlp_dtype", C.c_int32),
         ("elem_s", C.c_void_p),
     ]
@@ -116,16 +115,9 @@ SYMBOLS = {
     "pf_graph_destroy": (C.c_int, [C.c_void_p]),
     "pf_gd_iterations_timed": (C.c_int, [_PP, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),
     "pf_loss_and_grads": (C.c_int, [_PP, C.c_void_p]),
-    "pf_iface_pack": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_iface_unpack": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_iface_fix_residual": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
-    "pf_local_sums": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
-    "pf_adam_u": (C.c_int, [_PP, C.c_void_p]),
-    "pf_adam_theta": (C.c_int, [_PP, C.c_void_p]),
-    "pf_finalize_from": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "pf_shard_iface_forward": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
     "pf_shard_forward": (C.c_int, [_PP, C.c_void_p]),
     "pf_shard_backward": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_shard_flush": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
     "pf_shard_update_interior": (C.c_int, [_PP, C.c_void_p]),
     "pf_shard_update_shared": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_kv_f64": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
@@ -139,10 +131,7 @@ SYMBOLS = {
     "pf_comm_destroy": (C.c_int, [C.c_void_p]),
     "pf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pf_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "pf_shard_iterations": (C.c_int, [_PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                      C.c_void_p]),
-    "pf_shard_graph_create": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
-                                        C.POINTER(C.c_void_p)]),
+    "pf_shard_iterations": (C.c_int, [_PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pf_diag_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),

@@ -7,13 +7,12 @@
 #include "pf_net32.h"
 
 // launchers from pf_mesh.hip
-int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s,
-                            const float* iface = nullptr);
+int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s);
 int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s);
 int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared = 0);
-int pf_launch_iface_forward(const pf_problem* p, float* iface, hipStream_t s);
-int pf_launch_shard_pack(const pf_problem* p, float* buf2, hipStream_t s);
-int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* sums3, hipStream_t s);
+int pf_launch_shard_pack(const pf_problem* p, float* buf2, const float* u2_local, hipStream_t s);
+int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* u2_local, hipStream_t s);
+int pf_launch_shard_flush(const pf_problem* p, const float* u2, hipStream_t s);
 int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s);
 int pf_launch_pack_theta(const pf_problem* p, hipStream_t s);
 int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s);
@@ -24,13 +23,7 @@ int pf_launch_adam(float* param, const float* grad, float* m, float* v, int n, i
                    double beta1, double beta2, double eps, hipStream_t s);
 int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s);
 int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s);
-int pf_launch_iface_pack(const pf_problem* p, const float* vec, float* iface, hipStream_t s);
-int pf_launch_iface_unpack(const pf_problem* p, const float* iface, float* vec, hipStream_t s);
-int pf_launch_iface_fix_residual(const pf_problem* p, const float* iface, hipStream_t s);
-int pf_launch_local_sums(const pf_problem* p, float* sums3, hipStream_t s);
-int pf_launch_adam_u(const pf_problem* p, hipStream_t s);
-int pf_launch_adam_theta(const pf_problem* p, hipStream_t s);
-int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, hipStream_t s);
+int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, int u2_lag, hipStream_t s);
 
 static thread_local char g_err[512] = "";
 
@@ -577,75 +570,26 @@ static int check_shared(const pf_problem* p) {
   if (rc) return rc;
   if (p->n_shared < 0 || p->n_iface < p->n_shared) return fail(PF_ERR_ARG, "bad interface sizes");
   if (p->n_shared > 0 && (!p->shared_dofs || !p->shared_slot)) return fail(PF_ERR_ARG, "null interface maps");
+  if (p->own_lo < 0 || p->own_hi < p->own_lo || p->own_hi > p->mesh.n_elems) return fail(PF_ERR_ARG, "bad own element range");
   return PF_OK;
 }
 
-int pf_iface_pack(const pf_problem* p, const float* vec, float* iface, void* stream) {
-  int rc = check_shared(p);
-  if (rc) return rc;
-  if (!vec || !iface) return fail(PF_ERR_ARG, "null vec / iface");
-  PF_TRY(pf_launch_iface_pack(p, vec, iface, (hipStream_t)stream), "pf_iface_pack");
-  return PF_OK;
-}
-
-int pf_iface_unpack(const pf_problem* p, const float* iface, float* vec, void* stream) {
-  int rc = check_shared(p);
-  if (rc) return rc;
-  if (!vec || !iface) return fail(PF_ERR_ARG, "null vec / iface");
-  PF_TRY(pf_launch_iface_unpack(p, iface, vec, (hipStream_t)stream), "pf_iface_unpack");
-  return PF_OK;
-}
-
-int pf_iface_fix_residual(const pf_problem* p, const float* iface, void* stream) {
-  int rc = check_shared(p);
-  if (rc) return rc;
-  if (!iface) return fail(PF_ERR_ARG, "null iface");
-  PF_TRY(pf_launch_iface_fix_residual(p, iface, (hipStream_t)stream), "pf_iface_fix_residual");
-  return PF_OK;
-}
-
-int pf_local_sums(const pf_problem* p, float* sums3, void* stream) {
-  int rc = check_shared(p);
-  if (rc) return rc;
-  if (!sums3) return fail(PF_ERR_ARG, "null sums3");
-  PF_TRY(pf_launch_local_sums(p, sums3, (hipStream_t)stream), "pf_local_sums");
-  return PF_OK;
-}
-
-int pf_adam_u(const pf_problem* p, void* stream) {
-  int rc = check_problem(p);
-  if (rc) return rc;
-  if (!p->grad_u || !p->m_u || !p->v_u) return fail(PF_ERR_ARG, "pf_adam_u: null grad_u / moments");
-  PF_TRY(pf_launch_adam_u(p, (hipStream_t)stream), "pf_adam_u");
-  return PF_OK;
-}
-
-int pf_adam_theta(const pf_problem* p, void* stream) {
-  int rc = check_problem(p);
-  if (rc) return rc;
-  if (p->n_theta_active > 0 && (!p->m_t || !p->v_t)) return fail(PF_ERR_ARG, "null Adam moments for theta");
-  PF_TRY(pf_launch_adam_theta(p, (hipStream_t)stream), "pf_adam_theta");
-  return PF_OK;
-}
-
-int pf_finalize_from(const pf_problem* p, const float* sums_r2d2, const float* sum_u2, void* stream) {
-  int rc = check_problem(p);
-  if (rc) return rc;
-  if (!sums_r2d2 || !sum_u2) return fail(PF_ERR_ARG, "null sums");
-  PF_TRY(pf_launch_finalize_from(p, sums_r2d2, sum_u2, (hipStream_t)stream), "pf_finalize_from");
-  return PF_OK;
-}
-
-int pf_shard_iface_forward(const pf_problem* p, float* iface1, void* stream) {
-  int rc = check_shared(p);
-  if (rc) return rc;
-  if (!iface1) return fail(PF_ERR_ARG, "null iface1");
-  if (p->n_iface_elems < 0 || (p->n_iface_elems > 0 && !p->iface_elems))
-    return fail(PF_ERR_ARG, "bad interface element list");
-  if (p->n_iface_elems > PF_MAX_IFACE_ELEMS)
-    return fail(PF_ERR_UNSUPPORTED, "more interface elements than PF_MAX_IFACE_ELEMS: run the full forward first");
-  PF_TRY(pf_launch_iface_forward(p, iface1, (hipStream_t)stream), "iface_forward");
-  return PF_OK;
+// The own elements as a problem of their own: the element-indexed arrays start at own_lo (node ids in the
+// connectivity are untouched), so the element-parallel kernels run on exactly the range whose gradients this rank owns.
+static pf_problem own_view(const pf_problem* p) {
+  pf_problem q = *p;
+  if (p->own_hi > 0) {
+    const int lo = p->own_lo;
+    q.mesh.conn += 2 * (size_t)lo;
+    q.mesh.egeo += 4 * (size_t)lo;
+    q.mesh.ecent += (size_t)p->mesh.dim * lo;
+    if (q.prop_e) q.prop_e += lo;
+    if (q.prop_a) q.prop_a += lo;
+    if (q.g_ea) q.g_ea += lo;
+    if (q.elem_s) q.elem_s += lo;
+    q.mesh.n_elems = p->own_hi - lo;
+  }
+  return q;
 }
 
 int pf_shard_forward(const pf_problem* p, void* stream) {
@@ -657,25 +601,26 @@ int pf_shard_forward(const pf_problem* p, void* stream) {
   return PF_OK;
 }
 
-int pf_shard_backward(const pf_problem* p, const float* iface1, float* buf2, void* stream) {
+int pf_shard_backward(const pf_problem* p, float* buf, const float* u2_local, void* stream) {
   int rc = check_shared(p);
   if (rc) return rc;
-  if (!iface1 || !buf2) return fail(PF_ERR_ARG, "null iface1 / buf2");
-  if (p->n_theta_active > 0 && p->grad_theta != buf2 + p->n_iface)
-    return fail(PF_ERR_ARG, "p->grad_theta must point at buf2 + n_iface");
+  if (!buf || !u2_local) return fail(PF_ERR_ARG, "null buf / u2_local");
+  if (p->n_theta_active > 0 && p->grad_theta != buf + p->n_iface)
+    return fail(PF_ERR_ARG, "p->grad_theta must point at buf + n_iface");
   hipStream_t s = (hipStream_t)stream;
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
-  PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, iface1), "node_residual");
+  PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
   if (any_net) {
-    const bool fuse_gea = p->wg_mode == PF_WG_MFMA44 || p->wg_mode == PF_WG_MFMA32;
-    const int first = p->net[0].enabled ? 0 : 1;
-    if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+    const pf_problem q = own_view(p);
+    const bool fuse_gea = q.wg_mode == PF_WG_MFMA44 || q.wg_mode == PF_WG_MFMA32;
+    const int first = q.net[0].enabled ? 0 : 1;
+    if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(&q, s), "elem_adjoint");
     for (int k = 0; k < 2; ++k)
-      if (p->net[k].enabled)
-        PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
-    PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
+      if (q.net[k].enabled)
+        PF_TRY(fuse_gea && k == first ? net_backward_gea(&q, k, s) : net_backward(&q, k, s), "net_backward");
+    PF_TRY(pf_launch_theta_stage1(&q, s), "theta_stage1");
   }
-  PF_TRY(pf_launch_shard_pack(p, buf2, s), "shard_pack");
+  PF_TRY(pf_launch_shard_pack(p, buf, u2_local, s), "shard_pack");
   return PF_OK;
 }
 
@@ -687,114 +632,28 @@ int pf_shard_update_interior(const pf_problem* p, void* stream) {
   return PF_OK;
 }
 
-int pf_shard_update_shared(const pf_problem* p, const float* buf2, float* sums3, void* stream) {
+int pf_shard_update_shared(const pf_problem* p, const float* buf, float* u2_local, void* stream) {
   int rc = check_shared(p);
   if (rc) return rc;
-  if (!buf2 || !sums3 || !p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null buffer");
+  if (!buf || !u2_local || !p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null buffer");
   if (p->n_theta_active > 0 && (!p->m_t || !p->v_t)) return fail(PF_ERR_ARG, "null Adam moments for theta");
-  PF_TRY(pf_launch_shard_update(p, buf2, sums3, (hipStream_t)stream), "shard_update");
+  hipStream_t s = (hipStream_t)stream;
+  PF_TRY(pf_launch_shard_update(p, buf, u2_local, s), "shard_update");
+  const float* tail = buf + p->n_iface + p->n_theta_active;
+  PF_TRY(pf_launch_finalize_from(p, tail, tail + 2, 1, s), "finalize_from");
+  return PF_OK;
+}
+
+int pf_shard_flush(const pf_problem* p, const float* u2_reduced, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!u2_reduced) return fail(PF_ERR_ARG, "null u2");
+  PF_TRY(pf_launch_shard_flush(p, u2_reduced, (hipStream_t)stream), "shard_flush");
   return PF_OK;
 }
 
 }  // extern "C"
-template <class F>
-static int capture_graph(hipStream_t s, F&& body, void** out) {
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess)
-    return fail(PF_ERR_HIP, "hipStreamBeginCapture failed");
-  const int rc = body();
-  const hipError_t e = hipStreamEndCapture(s, &graph);
-  if (rc != PF_OK) {
-    if (graph) hipGraphDestroy(graph);
-    return rc;
-  }
-  if (e != hipSuccess || !graph) return fail(PF_ERR_HIP, "hipStreamEndCapture failed");
-  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-    hipGraphDestroy(graph);
-    return fail(PF_ERR_HIP, "hipGraphInstantiate failed");
-  }
-  hipGraphDestroy(graph);
-  *out = (void*)exec;
-  return PF_OK;
-}
 extern "C" {
-
-// Phases B + C (+ the interior part of D) of one sharded iteration as ONE graph with the single-GPU
-// schedule's branches: the previous iteration's bookkeeping beside the forwards, grad_u + Adam(u) of the
-// dofs that are not shared beside backward #2 and the theta reduction.  Stream events between eager
-// launches cost ~9 us per record+wait pair on this runtime (measured: 35-40 us per iteration for the
-// four hops of an "overlapped" eager schedule), graph edges do not.
-int pf_shard_graph_create(const pf_problem* p, float* buf1, float* buf2, int with_finalize, void* stream,
-                          void** graph_out) {
-  int rc = check_shared(p);
-  if (rc) return rc;
-  if (!buf1 || !buf2 || !graph_out) return fail(PF_ERR_ARG, "pf_shard_graph_create: null argument");
-  if (!p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null Adam moments for u");
-  if (p->n_theta_active > 0 && p->grad_theta != buf2 + p->n_iface)
-    return fail(PF_ERR_ARG, "p->grad_theta must point at buf2 + n_iface");
-  hipStream_t s = (hipStream_t)stream;
-  hipStream_t side[2] = {nullptr, nullptr};
-  hipEvent_t ev[5];
-  int made = 0;
-  bool ok = hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&side[1], hipStreamNonBlocking) == hipSuccess;
-  for (; ok && made < 5; ++made)
-    if (hipEventCreateWithFlags(&ev[made], hipEventDisableTiming) != hipSuccess) break;
-  ok = ok && made == 5;
-  auto cleanup = [&]() {
-    for (int i = 0; i < made; ++i) hipEventDestroy(ev[i]);
-    for (int k = 0; k < 2; ++k)
-      if (side[k]) hipStreamDestroy(side[k]);
-  };
-  if (!ok) {
-    cleanup();
-    return fail(PF_ERR_HIP, "pf_shard_graph_create: stream/event creation failed");
-  }
-  const float* iface1 = buf1 + 3;
-  const float* r2d2 = buf2 + p->n_iface + p->n_theta_active;
-  hipStream_t fin = side[0], gu = side[1];
-  rc = capture_graph(s, [&]() -> int {
-    const bool any_net = p->net[0].enabled || p->net[1].enabled;
-    const bool fuse_gea = any_net && (p->wg_mode == PF_WG_MFMA44 || p->wg_mode == PF_WG_MFMA32);
-    const int first = p->net[0].enabled ? 0 : 1;
-    // branch `fin`: bookkeeping of the previous iteration from the reduced sums (buf1[2], tail of buf2)
-    if (with_finalize) {
-      if (cap_edge(ev[0], s, fin) != PF_OK) return PF_ERR_HIP;
-      PF_TRY(pf_launch_finalize_from(p, r2d2, buf1 + 2, fin), "finalize_from");
-      if (hipEventRecord(ev[1], fin) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    }
-    for (int k = 0; k < 2; ++k)
-      if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
-    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, iface1), "node_residual");
-    if (any_net && !fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
-    bool forked = false;
-    auto fork_gradu = [&]() -> int {   // after the last reader of u; behind the bookkeeping (Adam scalars)
-      if (cap_edge(ev[2], s, gu) != PF_OK) return PF_ERR_HIP;
-      if (with_finalize && hipStreamWaitEvent(gu, ev[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-      PF_TRY(pf_launch_node_gradu(p, 1, gu, 1), "node_gradu");
-      if (hipEventRecord(ev[3], gu) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-      forked = true;
-      return PF_OK;
-    };
-    if (!fuse_gea) { int r = fork_gradu(); if (r != PF_OK) return r; }
-    if (any_net) {
-      for (int k = 0; k < 2; ++k) {
-        if (!p->net[k].enabled) continue;
-        PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
-        if (fuse_gea && k == first) { int r = fork_gradu(); if (r != PF_OK) return r; }
-      }
-      PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
-    }
-    // the pack kernel rewrites the tail of buf2 the bookkeeping reads
-    if (with_finalize && hipStreamWaitEvent(s, ev[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    PF_TRY(pf_launch_shard_pack(p, buf2, s), "shard_pack");
-    if (forked && hipStreamWaitEvent(s, ev[3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
-    return PF_OK;
-  }, graph_out);
-  cleanup();
-  return rc;
-}
 
 int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,
             double beta1, double beta2, double eps, void* stream) {

@@ -134,39 +134,29 @@ extern "C" {
   } while (0)
 
 // n_iter sharded iterations and the closing flush, everything in stream order on `stream`:
-//   A (eager)  ->  all-reduce(buf1)  ->  graph [B, C, interior part of D; pf_shard_graph_create]
-//   ->  all-reduce(buf2)  ->  E (eager)
-// graph_first / graph_next: the graph without / with the previous iteration's bookkeeping (NULL: the phases
-// are launched one by one, no branches).  buf1 = [0, 0, sum u^2 | iface f_int (n_iface)],
-// buf2 = [iface grad_u | grad_theta | r2, d2, 0].  Nothing here waits for the device.
-int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf1, float* buf2,
-                        void* graph_first, void* graph_next, void* stream) {
-  if (!p || !comm || !buf1 || !buf2 || n_iter < 0) return comm_fail(PF_ERR_ARG, "pf_shard_iterations", "bad argument");
+//   forward, backward (+ pack), interior update  ->  all-reduce(buf)  ->  interface update + bookkeeping
+// buf = [iface grad_u | grad_theta | r2, d2, u2 of the previous iteration], u2_local = this rank's last sum u_free^2.
+// ONE collective per iteration (a few hundred bytes to ~4 kB: latency bound); nothing here waits for the device.
+int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf, float* u2_local, void* stream) {
+  if (!p || !comm || !buf || !u2_local || n_iter < 0) return comm_fail(PF_ERR_ARG, "pf_shard_iterations", "bad argument");
   pf_comm* c = (pf_comm*)comm;
   hipStream_t s = (hipStream_t)stream;
-  const size_t n1 = 3 + (size_t)p->n_iface, n2 = (size_t)p->n_iface + (size_t)p->n_theta_active + 3;
-  float* iface1 = buf1 + 3;
-  const float* r2d2 = buf2 + p->n_iface + p->n_theta_active;
-  const bool graphs = graph_first && graph_next;
-  bool pending = false;
+  const size_t n = (size_t)p->n_iface + (size_t)p->n_theta_active + 3;
   for (int it = 0; it < n_iter; ++it) {
-    PF_RUN(pf_shard_iface_forward(p, iface1, stream));                  // A
-    PF_RUN(all_reduce(c, buf1, n1, s));                                 // (1)
-    if (graphs) {
-      PF_RUN(pf_graph_launch(pending ? graph_next : graph_first, stream));
-    } else {
-      PF_RUN(pf_shard_forward(p, stream));                              // B
-      if (pending) PF_RUN(pf_finalize_from(p, r2d2, buf1 + 2, stream)); // bookkeeping of the previous iteration
-      PF_RUN(pf_shard_backward(p, iface1, buf2, stream));               // C
-      PF_RUN(pf_shard_update_interior(p, stream));                      // D
-    }
-    PF_RUN(all_reduce(c, buf2, n2, s));                                 // (2)
-    PF_RUN(pf_shard_update_shared(p, buf2, buf1, stream));              // E
-    pending = true;
+    PF_RUN(pf_shard_forward(p, stream));
+    PF_RUN(pf_shard_backward(p, buf, u2_local, stream));
+    PF_RUN(pf_shard_update_interior(p, stream));
+    PF_RUN(all_reduce(c, buf, n, s));
+    PF_RUN(pf_shard_update_shared(p, buf, u2_local, stream));
   }
-  if (pending) {
-    PF_RUN(all_reduce(c, buf1, 3, s));                                  // flush: the last iteration's sum u^2
-    PF_RUN(pf_finalize_from(p, r2d2, buf1 + 2, stream));
+  if (n_iter > 0) {
+    // flush: the last iteration's sum u^2, reduced in the (free) last slot of buf — u2_local keeps the LOCAL sum,
+    // the next chunk's first all-reduce carries it again
+    float* slot = buf + n - 1;
+    if (hipMemcpyAsync(slot, u2_local, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return comm_fail(PF_ERR_HIP, "pf_shard_iterations", "hipMemcpyAsync failed");
+    PF_RUN(all_reduce(c, slot, 1, s));
+    PF_RUN(pf_shard_flush(p, slot, stream));
   }
   return PF_OK;
 }

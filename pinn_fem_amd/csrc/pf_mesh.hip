@@ -27,9 +27,11 @@
 namespace {
 
 // (K(theta) v)[node] by gather over incident elements, ascending element id
+// own_only (multi-GPU): skip the ghost elements (local ids outside [own_lo, own_hi)): their contributions to a
+// gradient belong to the rank that owns them
 template <int DIM>
 __device__ __forceinline__ void gather_kv(const pf_problem& P, const float* __restrict__ v, int node,
-                                          float* acc) {
+                                          float* acc, bool own_only = false) {
   const pf_mesh& M = P.mesh;
 #pragma unroll
   for (int c = 0; c < DIM; ++c) acc[c] = 0.f;
@@ -37,6 +39,7 @@ __device__ __forceinline__ void gather_kv(const pf_problem& P, const float* __re
   for (int idx = b; idx < e_; ++idx) {
     const int code = M.adj[idx];
     const int e = code >> 1, end = code & 1;
+    if (own_only && (e < P.own_lo || e >= P.own_hi)) continue;
     const int2 nn = reinterpret_cast<const int2*>(M.conn)[e];
     const ElemGeo g = load_geo(M.egeo, e);
     const float s = elem_stiffness(P, e, g.l0);
@@ -49,24 +52,13 @@ __device__ __forceinline__ void gather_kv(const pf_problem& P, const float* __re
   }
 }
 
-// position of `dof` in the ascending shared_dofs list (multi-GPU; the caller knows it is there)
-__device__ __forceinline__ int shared_index(const pf_problem& P, int dof) {
-  int lo = 0, hi = P.n_shared - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (P.shared_dofs[mid] < dof) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
 // ---- residual, losses, dL/df_int --------------------------------------------------------------
-// iface (multi-GPU, may be NULL): the all-reduced f_int of the shared dofs.  With it the shared dofs get
-// their complete f_int here and the OWNER rank counts them in the sums; without it they are left to
-// pf_iface_fix_residual (building-block path).
+// Multi-GPU: the local mesh carries the ghost elements of every shared node, so f_int is complete on every node of
+// an own element; a dof flagged PF_DOF_GHOST (owned by another rank, or a pure ghost node whose f_int is partial and
+// never used) is left out of the sums.
 template <int DIM>
 __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_residual(pf_problem P, float* f_int_out,
-                                                                    int compute_loss,
-                                                                    const float* __restrict__ iface) {
+                                                                    int compute_loss) {
   if (P.state->done) return;
   __shared__ float red[16];
   const pf_mesh& M = P.mesh;
@@ -79,11 +71,7 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_residual(pf_problem P,
     for (int c = 0; c < DIM; ++c) {
       const int dof = node * DIM + c;
       const unsigned fl = M.dof_flags[dof];
-      bool mine = !(fl & PF_DOF_SHARED);
-      if (iface && (fl & PF_DOF_SHARED)) {
-        f[c] = iface[P.shared_slot[shared_index(P, dof)]];
-        mine = !(fl & PF_DOF_GHOST);
-      }
+      const bool mine = !(fl & PF_DOF_GHOST);
       if (f_int_out) f_int_out[dof] = f[c];
       if (!compute_loss) continue;
       float gf = 0.f;
@@ -263,9 +251,11 @@ __global__ __launch_bounds__(256) void k_pack_theta(pf_problem P) {
 // mode 1: losses + gradient reduction only (autograd binding).  One block of 1024 threads.
 // ext_rd / ext_u2 (multi-GPU): globally reduced [sum r^2, sum d^2] and [sum u_free^2] to use instead of
 // this rank's block partials (which already belong to the next iteration when this runs).
+// u2_lag (multi-GPU): ext_u2 is the sum of the PREVIOUS iteration (it travelled on this iteration's all-reduce):
+// it completes the previous history row; this iteration's u_norm is filled in by the next call (or by k_shard_flush).
 __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, int mode, int with_theta,
                                                    const float* __restrict__ ext_rd,
-                                                   const float* __restrict__ ext_u2) {
+                                                   const float* __restrict__ ext_u2, int u2_lag) {
   pf_state* S = P.state;
   if (S->done) return;
   extern __shared__ float new_theta[];  // n_theta_active floats
@@ -334,7 +324,8 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
   const int it = S->iter;  // 0-based index of the iteration just completed
   if (P.hist && it < P.max_iter) {
     float* h = P.hist + (size_t)it * PF_HIST_COLS;
-    h[0] = loss; h[1] = loss_p; h[2] = loss_d; h[3] = un; h[4] = rn; h[5] = (float)tn;
+    h[0] = loss; h[1] = loss_p; h[2] = loss_d; h[3] = u2_lag ? 0.f : un; h[4] = rn; h[5] = (float)tn;
+    if (u2_lag && it > 0) h[3 - PF_HIST_COLS] = un;                     // the previous row's u_norm
   }
   S->iter = it + 1;
   if (it > 10) {                                                         // :341-355
@@ -353,123 +344,13 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
 }
 
 // ---- multi-GPU shard interface -------------------------------------------------------------------
-__global__ void k_iface_pack(pf_problem P, const float* __restrict__ vec, float* __restrict__ iface) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < P.n_shared) iface[P.shared_slot[k]] = vec[P.shared_dofs[k]];
-}
-
-__global__ void k_iface_unpack(pf_problem P, const float* __restrict__ iface, float* __restrict__ vec) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < P.n_shared) vec[P.shared_dofs[k]] = iface[P.shared_slot[k]];
-}
-
-// one block; the extra partial slot sits right after the node kernels' block partials
-__global__ __launch_bounds__(256) void k_iface_fix_residual(pf_problem P, const float* __restrict__ iface,
-                                                             int slot) {
-  if (P.state->done) return;
-  __shared__ float red[16];
-  const pf_mesh& M = P.mesh;
-  float sum_r2 = 0.f, sum_d2 = 0.f;
-  for (int k = threadIdx.x; k < P.n_shared; k += blockDim.x) {
-    const int dof = P.shared_dofs[k];
-    const unsigned fl = M.dof_flags[dof];
-    const bool owner = !(fl & PF_DOF_GHOST);
-    float gf = 0.f;
-    if (!(fl & PF_DOF_FIXED)) {
-      const float r = iface[P.shared_slot[k]] - P.lam * M.f_ext[dof];
-      if (owner) sum_r2 += r * r;
-      gf = P.alpha_physics * r;
-    }
-    P.g_f[dof] = gf;
-    if (owner && P.use_data && (fl & PF_DOF_MEASURED)) {
-      const float d = M.meas_val[dof] - P.u[dof];
-      sum_d2 += d * d;
-    }
-  }
-  const float t0 = pf_block_sum(sum_r2, red);
-  const float t1 = pf_block_sum(sum_d2, red);
-  if (threadIdx.x == 0) {
-    P.partials[PF_PART_R2 + slot] = t0;
-    P.partials[PF_PART_D2 + slot] = t1;
-  }
-}
-
-// ---- phase A: the nets on the interface elements + partial f_int of the shared dofs -----------------
-// One property of one element with plain fmaf chains in exactly the order of the MFMA kernels
-// (pf_net44.hip: bias first, inputs ascending, four output chains; an f32 MFMA is a chain of fmaf), so the
-// value is bit for bit the one the full forward pass writes for the same element a moment later.
-__device__ float eval_net_scalar(const pf_problem& P, int which, int e) {
-  const pf_net& net = P.net[which];
-  if (!net.enabled) return net.scale;
-  const int hp = ((net.width + 3) / 4) * 4, L = net.n_hidden, in = net.in_dim;
-  const float* __restrict__ w = P.theta_pad + net.pad_off;
-  float x[4] = {P.lam, 0.f, 0.f, 0.f};
-  for (int c = 1; c < in; ++c) x[c] = P.mesh.ecent[(size_t)e * (in - 1) + (c - 1)];
-  float ha[32], hb[32];
-  for (int j = 0; j < hp; ++j) {
-    float acc = fmaf(w[j * 4 + in], 1.0f, 0.f);
-    for (int c = 0; c < in; ++c) acc = fmaf(w[j * 4 + c], x[c], acc);
-    ha[j] = pf_tanh(acc);
-  }
-  float* hin = ha;
-  float* hout = hb;
-  for (int l = 2; l <= L; ++l) {
-    const float* __restrict__ wl = w + pf_pad_wh(hp, l);
-    for (int j = 0; j < hp; ++j) {
-      float acc = fmaf(wl[j * (hp + 4) + hp], 1.0f, 0.f);
-      for (int k = 0; k < hp; ++k) acc = fmaf(wl[j * (hp + 4) + k], hin[k], acc);
-      hout[j] = pf_tanh(acc);
-    }
-    float* t = hin; hin = hout; hout = t;
-  }
-  const float* __restrict__ wo = w + pf_pad_wo(hp, L);
-  float ao[4] = {wo[hp], 0.f, 0.f, 0.f};
-  for (int k = 0; k < hp; ++k) ao[(k + 1) % 4] = fmaf(wo[k], hin[k], ao[(k + 1) % 4]);
-  const float z = (ao[0] + ao[1]) + (ao[2] + ao[3]);
-  return (net.positive ? pf_softplus(z) : z) * net.scale;
-}
-
+// ---- tail of the rank-local part of a sharded iteration: theta stage 2 (no Adam) into grad_theta (inside buf),
+// this rank's share of grad_u on the interface dofs (OWN elements only; the data term by the owner), local loss sums:
+//   buf = [iface grad_u (n_iface) | grad_theta (n_theta_active) | sum r^2, sum d^2, sum u_free^2 of the PREVIOUS
+//          iteration (u2_local, written by k_shard_update)]                              => the iteration's ONE all-reduce
 template <int DIM>
-__global__ __launch_bounds__(256) void k_iface_forward(pf_problem P, float* __restrict__ iface) {
-  if (P.state->done) return;
-  __shared__ float sE[PF_MAX_IFACE_ELEMS], sA[PF_MAX_IFACE_ELEMS];
-  const pf_mesh& M = P.mesh;
-  for (int k = threadIdx.x; k < P.n_iface; k += blockDim.x) iface[k] = 0.f;
-  for (int i = threadIdx.x; i < P.n_iface_elems; i += blockDim.x) {
-    const int e = P.iface_elems[i];
-    sE[i] = eval_net_scalar(P, 0, e);
-    sA[i] = eval_net_scalar(P, 1, e);
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < P.n_shared; k += blockDim.x) {
-    const int dof = P.shared_dofs[k], node = dof / DIM, c = dof % DIM;
-    float acc[2] = {0.f, 0.f};
-    for (int idx = M.adj_ptr[node]; idx < M.adj_ptr[node + 1]; ++idx) {   // ascending element id, like gather_kv
-      const int code = M.adj[idx];
-      const int e = code >> 1, end = code & 1;
-      int lo = 0, hi = P.n_iface_elems - 1;
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (P.iface_elems[mid] < e) lo = mid + 1; else hi = mid;
-      }
-      const int2 nn = reinterpret_cast<const int2*>(M.conn)[e];
-      const ElemGeo g = load_geo(M.egeo, e);
-      const float s = (sE[lo] * sA[lo]) / g.l0;
-      float vi[2], vj[2], fe[2];
-      load_vec<DIM>(P.u, nn.x, vi);
-      load_vec<DIM>(P.u, nn.y, vj);
-      ke_rows_times<DIM>(g, s, end, vi, vj, fe, P.fe_mode);
-#pragma unroll
-      for (int q = 0; q < DIM; ++q) acc[q] += fe[q];
-    }
-    iface[P.shared_slot[k]] = acc[c];
-  }
-}
-
-// ---- phase C tail: theta stage 2 (no Adam) into grad_theta (inside buf2), partial grad_u of the shared
-// dofs, local loss sums: buf2 = [iface grad_u (n_iface) | grad_theta (n_theta_active) | r2, d2, 0] ------------
-template <int DIM>
-__global__ __launch_bounds__(1024) void k_shard_pack(pf_problem P, int nb_node, float* __restrict__ buf2) {
+__global__ __launch_bounds__(1024) void k_shard_pack(pf_problem P, int nb_node, float* __restrict__ buf2,
+                                                     const float* __restrict__ u2_local) {
   if (P.state->done) return;
   __shared__ double dred[16];
   const pf_mesh& M = P.mesh;
@@ -480,7 +361,7 @@ __global__ __launch_bounds__(1024) void k_shard_pack(pf_problem P, int nb_node, 
   for (int k = threadIdx.x; k < P.n_shared; k += blockDim.x) {
     const int dof = P.shared_dofs[k], node = dof / DIM, c = dof % DIM;
     float g[2];
-    gather_kv<DIM>(P, P.g_f, node, g);
+    gather_kv<DIM>(P, P.g_f, node, g, true);
     float gu = g[c];
     if (P.use_data && (M.dof_flags[dof] & PF_DOF_MEASURED)) {   // only the owner carries the flag
       const float d = M.meas_val[dof] - P.u[dof];
@@ -496,11 +377,13 @@ __global__ __launch_bounds__(1024) void k_shard_pack(pf_problem P, int nb_node, 
   const double ta = pf_block_sum_d(a, dred), tb = pf_block_sum_d(b, dred);
   if (threadIdx.x == 0) {
     float* tail = buf2 + P.n_iface + P.n_theta_active;
-    tail[0] = (float)ta; tail[1] = (float)tb; tail[2] = 0.f;
+    tail[0] = (float)ta; tail[1] = (float)tb; tail[2] = u2_local[0];
   }
 }
 
-// ---- phase E: Adam(theta) from the reduced gradient, Adam(u) of the shared dofs, sum u_free^2 -----------
+// ---- after the all-reduce: Adam(theta) from the reduced gradient, Adam(u) of the interface dofs (shared and ghost
+// nodes: every rank that holds a copy applies the same reduced gradient, so the copies stay bit-identical), and this
+// rank's sum u_free^2 over the dofs it owns -> u2_local[0] (rides on the NEXT iteration's all-reduce) -----------
 __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node, const float* __restrict__ buf2,
                                                        float* __restrict__ sums3) {
   PF_NO_CONTRACT
@@ -560,82 +443,16 @@ __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node
   }
   for (int i = threadIdx.x; i < nb_node; i += blockDim.x) c += (double)P.partials[PF_PART_U2 + i];
   const double tc = pf_block_sum_d(c, dred);
-  if (threadIdx.x == 0) { sums3[0] = 0.f; sums3[1] = 0.f; sums3[2] = (float)tc; }
+  if (threadIdx.x == 0) sums3[0] = (float)tc;
 }
 
-__global__ __launch_bounds__(1024) void k_local_sums(pf_problem P, int nb, float* __restrict__ sums3) {
-  __shared__ double dred[16];
-  double a = 0.0, b = 0.0, c = 0.0;
-  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
-    a += (double)P.partials[PF_PART_R2 + i];
-    b += (double)P.partials[PF_PART_D2 + i];
-  }
-  const int nbu = nb - (P.n_shared > 0 ? 1 : 0);  // the u^2 partials have no interface slot
-  for (int i = threadIdx.x; i < nbu; i += blockDim.x) c += (double)P.partials[PF_PART_U2 + i];
-  const double ta = pf_block_sum_d(a, dred), tb = pf_block_sum_d(b, dred), tc = pf_block_sum_d(c, dred);
-  if (threadIdx.x == 0) { sums3[0] = (float)ta; sums3[1] = (float)tb; sums3[2] = (float)tc; }
-}
-
-// Adam on u from a given gradient + clamp + ||u_free||^2 partials (owned dofs only)
-__global__ __launch_bounds__(PF_NODE_THREADS) void k_adam_u(pf_problem P) {
-  PF_NO_CONTRACT
-  if (P.state->done) return;
-  __shared__ float red[16];
-  const pf_mesh& M = P.mesh;
-  const float step_size = P.state->step_size_u, bc2s = P.state->bc2_sqrt;
-  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
-  const float eps = (float)P.eps;
-  float sum_u2 = 0.f;
-  for (int dof = blockIdx.x * blockDim.x + threadIdx.x; dof < M.n_dofs; dof += gridDim.x * blockDim.x) {
-    const unsigned fl = M.dof_flags[dof];
-    float uo = P.u[dof];
-    if (fl & PF_DOF_FIXED) {               // dead Adam state of fixed dofs: see k_node_gradu
-      if (uo != 0.f) P.u[dof] = 0.f;
-      continue;
-    }
-    const float gu = P.grad_u[dof];
-    float m = P.m_u[dof], v = P.v_u[dof];
-    m = m + b1w * (gu - m);
-    v = v * b2;
-    v = v + (b2w * gu) * gu;
-    const float denom = sqrtf(v) / bc2s + eps;
-    uo = uo + (-step_size) * (m / denom);
-    if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
-    P.m_u[dof] = m;
-    P.v_u[dof] = v;
-    P.u[dof] = uo;
-  }
-  const float t = pf_block_sum(sum_u2, red);
-  if (threadIdx.x == 0) P.partials[PF_PART_U2 + blockIdx.x] = t;
-}
-
-__global__ __launch_bounds__(1024) void k_adam_theta(pf_problem P) {
-  PF_NO_CONTRACT
-  if (P.state->done) return;
-  __shared__ float scratch[64];
-  extern __shared__ float new_theta_dyn[];
-  float* new_theta = P.wg_mode == PF_WG_MFMA32 ? new_theta_dyn : nullptr;
-  const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
-  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
-  const float eps = (float)P.eps;
-  for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
-    const float g = P.grad_theta[q];
-    float m = P.m_t[q], v = P.v_t[q], th = P.theta[q];
-    m = m + b1w * (g - m);
-    v = v * b2;
-    v = v + (b2w * g) * g;
-    const float denom = sqrtf(v) / bc2s + eps;
-    th = th + (-step_size) * (m / denom);
-    P.m_t[q] = m;
-    P.v_t[q] = v;
-    P.theta[q] = th;
-    P.theta_pad[P.pad_index[q]] = th;
-    if (new_theta) new_theta[q] = th;
-  }
-  if (new_theta) {
-    __syncthreads();
-    pack_net_ops(P, new_theta, scratch);
-  }
+// end of a chunk of sharded iterations: the last iteration's reduced sum u_free^2 completes the last history row
+__global__ void k_shard_flush(pf_problem P, const float* __restrict__ u2) {
+  pf_state* S = P.state;
+  const int it = S->iter;            // iterations completed
+  const float un = sqrtf(u2[0]);
+  S->u_norm = un;
+  if (P.hist && it >= 1 && it <= P.max_iter) P.hist[(size_t)(it - 1) * PF_HIST_COLS + 3] = un;
 }
 
 __global__ void k_reset(pf_problem P) {
@@ -737,13 +554,12 @@ int pf_node_blocks(int n_nodes) {
   return nb;
 }
 
-int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s,
-                            const float* iface) {
+int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s) {
   const int nb = pf_node_blocks(p->mesh.n_nodes);
   if (p->mesh.dim == 2)
-    hipLaunchKernelGGL(k_node_residual<2>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss, iface);
+    hipLaunchKernelGGL(k_node_residual<2>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss);
   else
-    hipLaunchKernelGGL(k_node_residual<1>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss, iface);
+    hipLaunchKernelGGL(k_node_residual<1>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss);
   return PF_CHECK_LAUNCH();
 }
 
@@ -807,7 +623,7 @@ int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_
     return PF_ERR_UNSUPPORTED;
   }
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), lds, s, *p, nb_node, mode, wt,
-                     (const float*)nullptr, (const float*)nullptr);
+                     (const float*)nullptr, (const float*)nullptr, 0);
   return PF_CHECK_LAUNCH();
 }
 
@@ -842,56 +658,23 @@ int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s) {
 }
 
 // ---- multi-GPU launchers ---------------------------------------------------------------------------
-int pf_launch_iface_pack(const pf_problem* p, const float* vec, float* iface, hipStream_t s) {
-  if (p->n_iface > 0 && hipMemsetAsync(iface, 0, (size_t)p->n_iface * sizeof(float), s) != hipSuccess) return PF_ERR_HIP;
-  if (p->n_shared > 0)
-    hipLaunchKernelGGL(k_iface_pack, dim3((p->n_shared + 255) / 256), dim3(256), 0, s, *p, vec, iface);
-  return PF_CHECK_LAUNCH();
-}
-int pf_launch_iface_unpack(const pf_problem* p, const float* iface, float* vec, hipStream_t s) {
-  if (p->n_shared > 0)
-    hipLaunchKernelGGL(k_iface_unpack, dim3((p->n_shared + 255) / 256), dim3(256), 0, s, *p, iface, vec);
-  return PF_CHECK_LAUNCH();
-}
-int pf_launch_iface_fix_residual(const pf_problem* p, const float* iface, hipStream_t s) {
-  const int slot = pf_node_blocks(p->mesh.n_nodes);
-  hipLaunchKernelGGL(k_iface_fix_residual, dim3(1), dim3(256), 0, s, *p, iface, slot);
-  return PF_CHECK_LAUNCH();
-}
-int pf_launch_iface_forward(const pf_problem* p, float* iface, hipStream_t s) {
-  if (p->mesh.dim == 2) hipLaunchKernelGGL(k_iface_forward<2>, dim3(1), dim3(256), 0, s, *p, iface);
-  else hipLaunchKernelGGL(k_iface_forward<1>, dim3(1), dim3(256), 0, s, *p, iface);
-  return PF_CHECK_LAUNCH();
-}
-int pf_launch_shard_pack(const pf_problem* p, float* buf2, hipStream_t s) {
+int pf_launch_shard_pack(const pf_problem* p, float* buf2, const float* u2_local, hipStream_t s) {
   const int nb = pf_node_blocks(p->mesh.n_nodes);
-  if (p->mesh.dim == 2) hipLaunchKernelGGL(k_shard_pack<2>, dim3(1), dim3(1024), 0, s, *p, nb, buf2);
-  else hipLaunchKernelGGL(k_shard_pack<1>, dim3(1), dim3(1024), 0, s, *p, nb, buf2);
+  if (p->mesh.dim == 2) hipLaunchKernelGGL(k_shard_pack<2>, dim3(1), dim3(1024), 0, s, *p, nb, buf2, u2_local);
+  else hipLaunchKernelGGL(k_shard_pack<1>, dim3(1), dim3(1024), 0, s, *p, nb, buf2, u2_local);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* sums3, hipStream_t s) {
+int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* u2_local, hipStream_t s) {
   const int nb = pf_node_blocks(p->mesh.n_nodes);
   const size_t lds = p->wg_mode == PF_WG_MFMA32 ? (size_t)p->n_theta_active * sizeof(float) : 0;
-  hipLaunchKernelGGL(k_shard_update, dim3(1), dim3(1024), lds, s, *p, nb, buf2, sums3);
+  hipLaunchKernelGGL(k_shard_update, dim3(1), dim3(1024), lds, s, *p, nb, buf2, u2_local);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_local_sums(const pf_problem* p, float* sums3, hipStream_t s) {
-  const int nb = pf_node_blocks(p->mesh.n_nodes) + (p->n_shared > 0 ? 1 : 0);
-  hipLaunchKernelGGL(k_local_sums, dim3(1), dim3(1024), 0, s, *p, nb, sums3);
+int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, int u2_lag, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, *p, 0, 0, 0, rd, u2, u2_lag);
   return PF_CHECK_LAUNCH();
 }
-int pf_launch_adam_u(const pf_problem* p, hipStream_t s) {
-  const int nb = pf_node_blocks(p->mesh.n_nodes);
-  hipLaunchKernelGGL(k_adam_u, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p);
-  return PF_CHECK_LAUNCH();
-}
-int pf_launch_adam_theta(const pf_problem* p, hipStream_t s) {
-  if (p->n_theta_active <= 0) return PF_OK;
-  const size_t lds = p->wg_mode == PF_WG_MFMA32 ? (size_t)p->n_theta_active * sizeof(float) : 0;
-  hipLaunchKernelGGL(k_adam_theta, dim3(1), dim3(1024), lds, s, *p);
-  return PF_CHECK_LAUNCH();
-}
-int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, *p, 0, 0, 0, rd, u2);
+int pf_launch_shard_flush(const pf_problem* p, const float* u2, hipStream_t s) {
+  hipLaunchKernelGGL(k_shard_flush, dim3(1), dim3(1), 0, s, *p, u2);
   return PF_CHECK_LAUNCH();
 }

@@ -3,27 +3,23 @@
 The reference is single-process (no collectives, no devices); this module is the
 build's answer to BASELINE.json's "shard elements across the 8 GPUs of one node".
 
-Partition: contiguous element ranges.  A node whose elements live on several ranks is SHARED; every
-sharing rank keeps a copy of its u and Adam state, and the lowest sharing rank OWNS it (counts it in
-global sums, adds its data-loss term).  Per GD iteration there are TWO small all-reduces, the floor
-for this partition (one exchange before the residual, one after the backward), in stream order:
-  (1) [sum u_free^2 of the PREVIOUS iteration | partial f_int of the shared dofs]
-      The few elements touching a shared node are evaluated first (phase A, one tiny kernel with the
-      arithmetic of the full net kernels, bit for bit), so the exchange does not wait for the forward
-      pass over all elements (phase B).
-  (2) [partial grad_u of the shared dofs | grad_theta | sum r^2, sum d^2]
-      after the backward (phase C) and grad_u + Adam(u) of every dof that is NOT shared (phase D);
-      Adam(theta) and the shared dofs follow (phase E).
-Measured on MI355X: hiding the two collectives on a second stream costs more than it saves (cross-stream
-event pairs between eager launches ~9 us each on this runtime; the vectors are <= 4 kB, i.e. pure
-latency), and so does one hipGraph replay per iteration; everything runs in stream order on one stream.
-The u-norm is a monitor only, so it rides on the next iteration's first collective and the
-bookkeeping kernel of iteration t (history row, stop test, next Adam scalars) runs right after that
-collective, before anything of iteration t+1 that could change state; a chunk ends with one flush
-collective.
-Everything else (u, f_int, Adam-u state, residual) stays sharded; theta and its Adam state are
-replicated and stay bit-identical because every rank applies the same reduced gradient.
-For a 1-D chain cut into G shards the interface has 2(G-1) dofs, so the traffic is ~4 kB per
+Partition: contiguous element ranges.  A node whose elements live on several ranks is SHARED.  Besides its own
+elements a rank holds one ring of GHOST elements: every element of another rank that touches one of its shared
+nodes (and, with them, the ghost nodes at their far ends).  Consequences:
+  * the internal force, the residual and dL/df_int of every node of an own element are complete on the rank itself —
+    nothing is exchanged before the residual;
+  * gradients are taken over the own elements only (MLP backward, grad_u), so every element contributes exactly once;
+  * the INTERFACE nodes = shared nodes plus the other nodes of the elements around them.  Their grad_u is the sum of
+    the shares of the ranks that own an incident element; every rank holding a copy (as a node of an own or of a ghost
+    element) then applies the same Adam step, so the copies — unknowns and Adam moments — stay bit-identical.
+Per GD iteration there is ONE small all-reduce, in stream order after the rank-local kernels:
+      [share of grad_u on the interface dofs | grad_theta | sum r^2, sum d^2 | sum u_free^2 of the PREVIOUS iteration]
+followed by Adam(theta), Adam(u) on the interface dofs and the iteration's bookkeeping (history row, stop test, next
+Adam scalars) from the reduced sums.  The u-norm is a monitor only (not part of the stop test, solver.py:341-355), so
+it travels one iteration late and completes the previous history row; a chunk ends with a one-float flush.
+Everything else (u, f_int, Adam-u state, residual) stays sharded; theta and its Adam state are replicated and stay
+bit-identical because every rank applies the same reduced gradient (the initial theta is broadcast from rank 0).
+For a 1-D chain cut into G shards the interface has 3(G-1) nodes: ~6(G-1) floats + grad_theta (<= 4 kB) per
 iteration regardless of N — latency-bound, as SURVEY.md §5/§8(e) predicts.
 
 The iteration driver (`run_iterations`) only talks to a ShardBackend; the product backend is
@@ -51,16 +47,18 @@ from .plan import HostPlan, build_host_plan
 class Shard:
     rank: int
     world: int
-    elem_lo: int
+    elem_lo: int                 # own elements: global ids [elem_lo, elem_hi)
     elem_hi: int
+    elems_global: np.ndarray     # global id of each LOCAL element (own + ghost), ascending
+    own_lo: int                  # the own elements are the local range [own_lo, own_hi)
+    own_hi: int
     nodes_global: np.ndarray     # global node id of each local node (ascending)
     elements_local: np.ndarray   # (n_local_elems, 2) in local node numbering
-    shared_dofs: np.ndarray      # local dof indices shared with other ranks (ascending global dof)
+    shared_dofs: np.ndarray      # local dof indices of the interface nodes present here (ascending global dof)
     shared_slot: np.ndarray      # their positions in the global interface vector
-    ghost_mask: np.ndarray       # bool per local dof: shared and owned by a lower rank
+    ghost_mask: np.ndarray       # bool per local dof: owned by another rank (lower sharer, or a pure ghost node)
     n_iface: int
     dim: int
-    iface_elems: Optional[np.ndarray] = None   # local element ids touching a shared node (ascending)
 
 
 def element_ranges(n_elems: int, world: int) -> List[Tuple[int, int]]:
@@ -82,35 +80,48 @@ def partition_mesh(elements: np.ndarray, n_nodes: int, dim: int, rank: int, worl
     erank = np.empty(n_elems, dtype=np.int64)
     for r, (lo, hi) in enumerate(ranges):
         erank[lo:hi] = r
-    rmin = np.full(n_nodes, world, dtype=np.int64)
+    rmin = np.full(n_nodes, world, dtype=np.int64)         # lowest / highest rank owning an incident element
     rmax = np.full(n_nodes, -1, dtype=np.int64)
     for col in range(2):
         np.minimum.at(rmin, elements[:, col], erank)
         np.maximum.at(rmax, elements[:, col], erank)
-    shared_nodes = np.flatnonzero((rmax > rmin) & (rmax >= 0))       # ascending global id
+    shared = (rmax > rmin) & (rmax >= 0)
+    # interface nodes: shared nodes and every node of an element that touches one (ascending global id)
+    ring = shared[elements].any(axis=1) if n_elems else np.zeros(0, dtype=bool)
+    iface = shared.copy()
+    if ring.any():
+        iface[elements[ring].reshape(-1)] = True
+    iface_nodes = np.flatnonzero(iface)
+    slot_of = -np.ones(n_nodes, dtype=np.int64)
+    slot_of[iface_nodes] = np.arange(iface_nodes.size)
     lo, hi = ranges[rank]
-    loc = elements[lo:hi]
+    own_nodes = np.zeros(n_nodes, dtype=bool)
+    if hi > lo:
+        own_nodes[elements[lo:hi].reshape(-1)] = True
+    # ghost elements: other ranks' elements touching a shared node of mine
+    mine_shared = shared & own_nodes
+    ghost = (mine_shared[elements].any(axis=1) & (erank != rank)) if n_elems else np.zeros(0, dtype=bool)
+    local_mask = ghost.copy()
+    local_mask[lo:hi] = True
+    elems_global = np.flatnonzero(local_mask)               # ascending: ghosts below | own | ghosts above
+    own_lo = int(np.searchsorted(elems_global, lo))
+    own_hi = own_lo + (hi - lo)
+    assert own_hi <= elems_global.size and (hi == lo or (elems_global[own_lo] == lo and elems_global[own_hi - 1] == hi - 1))
+    loc = elements[elems_global]
     nodes_global = np.unique(loc.reshape(-1)) if loc.size else np.zeros(0, dtype=np.int64)
     elements_local = np.searchsorted(nodes_global, loc) if loc.size else np.zeros((0, 2), dtype=np.int64)
-    # interface numbering: shared node k -> slots k*dim .. k*dim+dim-1
-    mine = np.isin(shared_nodes, nodes_global)
-    my_shared_nodes = shared_nodes[mine]
-    k_idx = np.flatnonzero(mine)
-    local_idx = np.searchsorted(nodes_global, my_shared_nodes)
     comp = np.arange(dim)
+    my_iface = iface[nodes_global]
+    local_idx = np.flatnonzero(my_iface)
     shared_dofs = (local_idx[:, None] * dim + comp[None, :]).reshape(-1)
-    shared_slot = (k_idx[:, None] * dim + comp[None, :]).reshape(-1)
-    ghost = np.zeros(len(nodes_global) * dim, dtype=bool)
-    not_owner = rmin[my_shared_nodes] != rank
-    ghost_nodes = local_idx[not_owner]
-    if ghost_nodes.size:
-        ghost[(ghost_nodes[:, None] * dim + comp[None, :]).reshape(-1)] = True
-    touches = np.isin(loc, my_shared_nodes).any(axis=1) if loc.size else np.zeros(0, dtype=bool)
-    return Shard(rank=rank, world=world, elem_lo=lo, elem_hi=hi, nodes_global=nodes_global,
-                 elements_local=elements_local, shared_dofs=shared_dofs.astype(np.int32),
-                 shared_slot=shared_slot.astype(np.int32), ghost_mask=ghost,
-                 n_iface=int(len(shared_nodes) * dim), dim=dim,
-                 iface_elems=np.flatnonzero(touches).astype(np.int32))
+    shared_slot = (slot_of[nodes_global[local_idx]][:, None] * dim + comp[None, :]).reshape(-1)
+    # owner of a node: the lowest rank that owns an incident element; everybody else holds a copy
+    not_owner = rmin[nodes_global] != rank
+    ghost_dofs = np.repeat(not_owner, dim)
+    return Shard(rank=rank, world=world, elem_lo=lo, elem_hi=hi, elems_global=elems_global, own_lo=own_lo,
+                 own_hi=own_hi, nodes_global=nodes_global, elements_local=elements_local,
+                 shared_dofs=shared_dofs.astype(np.int32), shared_slot=shared_slot.astype(np.int32),
+                 ghost_mask=ghost_dofs, n_iface=int(iface_nodes.size * dim), dim=dim)
 
 
 def shard_host_plan(shard: Shard, nodes, loads, fixed_dofs, measured_disp, measured_dofs,
@@ -150,19 +161,19 @@ def shard_host_plan(shard: Shard, nodes, loads, fixed_dofs, measured_disp, measu
 # ---------------------------------------------------------------------------------------------------
 class ShardBackend:
     """What the driver needs from one rank's local problem.  All tensors live on `device`.
-    Buffers: buf1 = [3 floats: 0, 0, sum u_free^2 | partial f_int of the shared dofs (n_iface)],
-             buf2 = [partial grad_u of the shared dofs (n_iface) | grad_theta (n_theta_active) | sum r^2, sum d^2, 0].
+    Buffers: buf = [share of grad_u on the interface dofs (n_iface) | grad_theta (n_theta_active) |
+                    sum r^2, sum d^2, sum u_free^2 of the previous iteration],
+             u2  = [this rank's sum u_free^2 of the iteration just finished].
     Phases of one iteration (stream-ordered; see the module docstring):"""
     device: torch.device
     n_iface: int
     n_theta_active: int
 
-    def iface_forward(self, iface: torch.Tensor): ...     # A: interface elements -> iface[slot] (else 0)
-    def forward(self): ...                                # B: nets on all elements
-    def backward(self, iface: torch.Tensor, buf2: torch.Tensor): ...   # C: residual (reduced f_int), backward, pack buf2
-    def update_interior(self): ...                        # D: grad_u + Adam(u) of the dofs that are not shared
-    def update_shared(self, buf2: torch.Tensor, sums3: torch.Tensor): ...  # E: Adam(theta), shared dofs; sums3[2]
-    def finalize(self, r2d2: torch.Tensor, u2: torch.Tensor): ...
+    def forward(self): ...                                # nets on all local elements (own + ghost)
+    def backward(self, buf: torch.Tensor, u2: torch.Tensor): ...   # residual, backward over own elements, pack buf
+    def update_interior(self): ...                        # grad_u + Adam(u) of the dofs that are not interface dofs
+    def update_shared(self, buf: torch.Tensor, u2: torch.Tensor): ...  # Adam(theta), interface dofs, bookkeeping; u2[0]
+    def flush(self, u2_reduced: torch.Tensor): ...        # last iteration's u-norm into the history
 
 
 def _all_reduce(t: torch.Tensor, group=None):
@@ -294,22 +305,20 @@ def destroy_rccl_comms():
 
 def run_iterations(backend: ShardBackend, n_iter: int, group=None,
                    bufs: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-    """n_iter GD iterations with the two collectives per iteration of the module docstring (+ one
-    flush at the end, so the device state is final when this returns).  On an RCCL process group the
-    HIP backend's iterations are issued by the C driver (pf_shard_iterations: kernels and ncclAllReduce
-    from one C loop, no Python between them); everything else goes through the Python schedule below."""
+    """n_iter GD iterations with ONE collective per iteration (+ a one-float flush at the end, so the device state is
+    final when this returns).  On an RCCL process group the HIP backend's iterations are issued by the C driver
+    (pf_shard_iterations: kernels and ncclAllReduce from one C loop, no Python between them); everything else goes
+    through the Python schedule below."""
     if bufs is None:
         bufs = getattr(backend, "bufs", None) or make_buffers(backend)
     eng = getattr(backend, "eng", None)
     comm = rccl_comm(backend, group) if n_iter > 0 else None
     if n_iter > 0:
-        backend.driver_used = "c-rccl" if (comm is not None and backend.early_iface) else "python"
-    if comm is not None and backend.early_iface:
-        g0, g1 = backend.graphs()
+        backend.driver_used = "c-rccl" if comm is not None else "python"
+    if comm is not None:
         with eng.on_stream():
             _capi.check(eng.lib.pf_shard_iterations(eng._ref(), comm, int(n_iter), bufs[0].data_ptr(),
-                                                    bufs[1].data_ptr(), g0, g1, eng._stream()),
-                        "pf_shard_iterations")
+                                                    bufs[1].data_ptr(), eng._stream()), "pf_shard_iterations")
         return bufs
     ctx = eng.on_stream() if eng is not None else contextlib.nullcontext()
     with ctx:   # kernels and collectives on one stream (the engine's)
@@ -317,103 +326,55 @@ def run_iterations(backend: ShardBackend, n_iter: int, group=None,
     return bufs
 
 
-def _run_iterations(backend, n_iter, group, buf1, buf2):
-    ni, nt = backend.n_iface, backend.n_theta_active
-    r2d2 = buf2[ni + nt:ni + nt + 2]
-    pending = False
+def _run_iterations(backend, n_iter, group, buf, u2):
     for _ in range(n_iter):
-        backend.iface_forward(buf1[3:])
-        _all_reduce(buf1, group)                 # (1) + the previous iteration's sum u^2 in buf1[2]
         backend.forward()
-        if pending:
-            backend.finalize(r2d2, buf1[2:3])    # bookkeeping of the previous iteration
-        backend.backward(buf1[3:], buf2)
+        backend.backward(buf, u2)
         backend.update_interior()
-        _all_reduce(buf2, group)                 # (2)
-        backend.update_shared(buf2, buf1[:3])
-        pending = True
-    if pending:
-        _all_reduce(buf1[:3], group)             # flush: the last iteration's sum u^2
-        backend.finalize(r2d2, buf1[2:3])
+        _all_reduce(buf, group)                  # THE collective of the iteration
+        backend.update_shared(buf, u2)
+    if n_iter > 0:
+        last = buf[-1:]                          # free slot: u2 keeps the LOCAL sum for the next chunk's first collective
+        last.copy_(u2)
+        _all_reduce(last, group)                 # flush: the last iteration's sum u^2
+        backend.flush(last)
 
 
 def make_buffers(backend: ShardBackend):
     dev = backend.device
     f32 = dict(dtype=torch.float32, device=dev)
-    return (torch.zeros(3 + backend.n_iface, **f32),
-            torch.zeros(backend.n_iface + backend.n_theta_active + 3, **f32))
+    return (torch.zeros(backend.n_iface + backend.n_theta_active + 3, **f32), torch.zeros(1, **f32))
 
 
 # ---------------------------------------------------------------------------------------------------
 # HIP backend
 # ---------------------------------------------------------------------------------------------------
 class HipShardBackend(ShardBackend):
-    """One rank's shard on its GPU: a HipEngine over the local sub-mesh plus the interface maps."""
+    """One rank's shard on its GPU: a HipEngine over the local sub-mesh (own + ghost elements) plus the interface maps."""
 
     def __init__(self, local_model, host_plan: HostPlan, shard: Shard, has_measurements: bool,
                  device=None, wg_mode=None, fe_mode=None):
         from .engine import HipEngine
         self.shard = shard
-        ie = shard.iface_elems if shard.iface_elems is not None else np.zeros(0, dtype=np.int32)
-        # phase A needs the interface elements in one block's LDS; a very long interface (a mesh cut
-        # across thousands of elements) falls back to "full forward, then gather": correct, no overlap
-        self.early_iface = len(ie) <= _capi.PF_MAX_IFACE_ELEMS
-        self.eng = HipEngine(local_model, device=device, host_plan=host_plan, wg_mode=wg_mode,
-                             fe_mode=fe_mode,
-                             iface=(shard.shared_dofs, shard.shared_slot, shard.n_iface,
-                                    ie if self.early_iface else None))
+        self.eng = HipEngine(local_model, device=device, host_plan=host_plan, wg_mode=wg_mode, fe_mode=fe_mode,
+                             iface=(shard.shared_dofs, shard.shared_slot, shard.n_iface, (shard.own_lo, shard.own_hi)))
         self.eng.has_measurements = has_measurements
         self.device = self.eng.device
         self.n_iface = shard.n_iface
         self.n_theta_active = self.eng.n_theta_active
-        self.fbuf = None if self.early_iface else torch.zeros(host_plan.n_dofs, dtype=torch.float32,
-                                                               device=self.device)
-        self.bufs = make_buffers(self)           # (buf1, buf2): fixed addresses, baked into the graphs
-        self._graphs = None                      # C driver only
+        self.bufs = make_buffers(self)           # (buf, u2): fixed addresses
 
     # -- solve_gd-level control ---------------------------------------------------------------------
     def begin(self, u_initial_local, lam, config, want_history=True, group=None):
-        self._drop_graphs()
         if self.eng.n_theta:
             # replicas of theta must be bit-identical on every rank (see broadcast_theta)
             with self.eng.on_stream():
                 broadcast_theta(self.eng.theta.flat, group)
         self.eng.begin(u_initial_local, lam, config, want_history=want_history)
-        # grad_theta is reduced straight into buf2, where the second collective reads it
-        self.eng.P.grad_theta = self.bufs[1].data_ptr() + 4 * self.n_iface
+        # grad_theta is reduced straight into buf, where the collective reads it
+        self.eng.P.grad_theta = self.bufs[0].data_ptr() + 4 * self.n_iface
         self.bufs[0].zero_()
-
-    def _drop_graphs(self):
-        if self._graphs:
-            for g in self._graphs:
-                if g:
-                    self.eng.lib.pf_graph_destroy(g)
-        self._graphs = None
-
-    def graphs(self):
-        """The two hipGraphs of pf_shard_graph_create (phases B..D without / with the previous
-        iteration's bookkeeping) for the C driver.  OFF by default: one graph replay per iteration
-        measured slower than the same kernels launched one by one (0.271 vs 0.226 ms per iteration at 10^6
-        elements, world_size 1, MI355X) — the replay's fixed cost is not amortised over one iteration the
-        way the single-GPU path amortises it over ten.  PINNFEM_SHARD_GRAPH=1 turns it on."""
-        if os.environ.get("PINNFEM_SHARD_GRAPH", "0") != "1":
-            return None, None
-        if self._graphs is None:
-            import ctypes as C
-            e = self.eng
-            buf1, buf2 = self.bufs
-            out = []
-            with e.on_stream():
-                for with_fin in (0, 1):
-                    g = C.c_void_p()
-                    _capi.check(e.lib.pf_shard_graph_create(e._ref(), buf1.data_ptr(), buf2.data_ptr(), with_fin,
-                                                            e._stream(), C.byref(g)), "pf_shard_graph_create")
-                    out.append(g)
-            self._graphs = out
-        return self._graphs[0], self._graphs[1]
-
-    def _phase(self, k, eager):
-        return eager()
+        self.bufs[1].zero_()
 
     def state(self):
         return self.eng.state()
@@ -423,59 +384,35 @@ class HipShardBackend(ShardBackend):
 
     # -- ShardBackend (Python driver: gloo tests, single-GPU rehearsal, fallback): one C call per phase ----
     def _check_bufs(self, *tensors):
-        buf1, buf2 = self.bufs
-        lo1, hi1 = buf1.data_ptr(), buf1.data_ptr() + 4 * buf1.numel()
-        lo2, hi2 = buf2.data_ptr(), buf2.data_ptr() + 4 * buf2.numel()
+        buf, u2 = self.bufs
+        spans = [(t.data_ptr(), t.data_ptr() + 4 * t.numel()) for t in (buf, u2)]
         for t in tensors:
             p = t.data_ptr()
-            if t.numel() and not (lo1 <= p < hi1 or lo2 <= p < hi2):
+            if t.numel() and not any(lo <= p < hi for lo, hi in spans):
                 raise ValueError("HipShardBackend works on its own collective buffers (backend.bufs)")
-
-    def _iface_ptr(self, iface):
-        # an empty view (world_size 1: no interface) has no address of its own
-        return iface.data_ptr() if iface.numel() else self.bufs[0].data_ptr() + 12
-
-    def iface_forward(self, iface):
-        e = self.eng
-        self._check_bufs(iface)
-        if not self.early_iface:
-            # fallback: full forward, partial f_int of every dof, pack the shared ones
-            s = e._stream()
-            _capi.check(e.lib.pf_shard_forward(e._ref(), s), "pf_shard_forward")
-            _capi.check(e.lib.pf_internal_force(e._ref(), e.u.data_ptr(), self.fbuf.data_ptr(), s), "pf_internal_force")
-            _capi.check(e.lib.pf_iface_pack(e._ref(), self.fbuf.data_ptr(), iface.data_ptr(), s), "pf_iface_pack")
-            return
-        self._phase(0, lambda: _capi.check(
-            e.lib.pf_shard_iface_forward(e._ref(), self._iface_ptr(iface), e._stream()), "pf_shard_iface_forward"))
 
     def forward(self):
         e = self.eng
-        if not self.early_iface:
-            return
-        self._phase(1, lambda: _capi.check(e.lib.pf_shard_forward(e._ref(), e._stream()), "pf_shard_forward"))
+        _capi.check(e.lib.pf_shard_forward(e._ref(), e._stream()), "pf_shard_forward")
 
-    def backward(self, iface, buf2):
+    def backward(self, buf, u2):
         e = self.eng
-        self._check_bufs(iface, buf2)
-        self._phase(2, lambda: _capi.check(
-            e.lib.pf_shard_backward(e._ref(), self._iface_ptr(iface), buf2.data_ptr(), e._stream()), "pf_shard_backward"))
+        self._check_bufs(buf, u2)
+        _capi.check(e.lib.pf_shard_backward(e._ref(), buf.data_ptr(), u2.data_ptr(), e._stream()), "pf_shard_backward")
 
     def update_interior(self):
         e = self.eng
-        self._phase(3, lambda: _capi.check(
-            e.lib.pf_shard_update_interior(e._ref(), e._stream()), "pf_shard_update_interior"))
+        _capi.check(e.lib.pf_shard_update_interior(e._ref(), e._stream()), "pf_shard_update_interior")
 
-    def update_shared(self, buf2, sums3):
+    def update_shared(self, buf, u2):
         e = self.eng
-        self._check_bufs(buf2, sums3)
-        self._phase(4, lambda: _capi.check(
-            e.lib.pf_shard_update_shared(e._ref(), buf2.data_ptr(), sums3.data_ptr(), e._stream()),
-            "pf_shard_update_shared"))
+        self._check_bufs(buf, u2)
+        _capi.check(e.lib.pf_shard_update_shared(e._ref(), buf.data_ptr(), u2.data_ptr(), e._stream()),
+                    "pf_shard_update_shared")
 
-    def finalize(self, r2d2, u2):
+    def flush(self, u2_reduced):
         e = self.eng
-        _capi.check(e.lib.pf_finalize_from(e._ref(), r2d2.data_ptr(), u2.data_ptr(), e._stream()),
-                    "pf_finalize_from")
+        _capi.check(e.lib.pf_shard_flush(e._ref(), u2_reduced.data_ptr(), e._stream()), "pf_shard_flush")
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -500,15 +437,11 @@ def build_shard_backend(model, measured_disp, measured_dofs, rank: int, world: i
 
 
 def assembled_f_int(backend: "HipShardBackend", lam: float, group=None) -> torch.Tensor:
-    """Local view of the fully assembled f_int (re-evaluating the nets): partial gather + interface sum."""
+    """Local view of the assembled f_int (re-evaluating the nets).  With the ghost elements of every shared node in the
+    local mesh it is complete on every node this rank owns (the only entries gather_global_vector takes); no exchange."""
     e = backend.eng
     with e.on_stream():
-        f = e.internal_force(lam=lam)
-        iface = torch.zeros(max(backend.n_iface, 1), dtype=torch.float32, device=backend.device)
-        _capi.check(e.lib.pf_iface_pack(e._ref(), f.data_ptr(), iface.data_ptr(), e._stream()), "pf_iface_pack")
-        _all_reduce(iface, group)
-        _capi.check(e.lib.pf_iface_unpack(e._ref(), iface.data_ptr(), f.data_ptr(), e._stream()), "pf_iface_unpack")
-    return f
+        return e.internal_force(lam=lam)
 
 
 def gather_global_vector(local: torch.Tensor, backend, n_dofs_global: int, group=None) -> np.ndarray:
@@ -528,9 +461,41 @@ def gather_global_vector(local: torch.Tensor, backend, n_dofs_global: int, group
 # ---------------------------------------------------------------------------------------------------
 # bench helper: weak-scaling chain, every rank builds only its own shard analytically
 # ---------------------------------------------------------------------------------------------------
+def chain_shard(n: int, rank: int, world: int) -> Shard:
+    """The shard of rank `rank` of a world*n-element chain (element e joins nodes e, e+1), built analytically: the same
+    record partition_mesh gives for that mesh (tests/test_dist_gloo.py checks it), without the global arrays."""
+    if world > 1 and n < 3:
+        raise ValueError("chain shards need at least 3 elements per rank")
+    e0 = rank * n
+    g_lo = e0 - 1 if rank > 0 else e0                     # first / last local ELEMENT (global id)
+    g_hi = e0 + n if rank < world - 1 else e0 + n - 1
+    elems_global = np.arange(g_lo, g_hi + 1)
+    nodes_global = np.arange(g_lo, g_hi + 2)
+    el = np.stack([elems_global - g_lo, elems_global - g_lo + 1], axis=1)
+    own_lo = e0 - g_lo
+    # interface nodes of cut k (between ranks k-1 and k, k = 1..world-1): k*n-1, k*n, k*n+1 -> slots 3(k-1)+0..2
+    sd, ss, ghost_nodes = [], [], []
+    for k in ([rank] if rank > 0 else []) + ([rank + 1] if rank < world - 1 else []):
+        for j, node in enumerate((k * n - 1, k * n, k * n + 1)):
+            loc = node - g_lo
+            sd += [2 * loc, 2 * loc + 1]
+            ss += [2 * (3 * (k - 1) + j), 2 * (3 * (k - 1) + j) + 1]
+            owner = k - 1 if j < 2 else k               # lowest rank owning an incident element
+            if owner != rank:
+                ghost_nodes.append(loc)
+    ghost = np.zeros(2 * nodes_global.size, dtype=bool)
+    for loc in ghost_nodes:
+        ghost[2 * loc:2 * loc + 2] = True
+    order = np.argsort(sd)
+    return Shard(rank=rank, world=world, elem_lo=e0, elem_hi=e0 + n, elems_global=elems_global, own_lo=own_lo,
+                 own_hi=own_lo + n, nodes_global=nodes_global, elements_local=el,
+                 shared_dofs=np.array(sd, dtype=np.int32)[order], shared_slot=np.array(ss, dtype=np.int32)[order],
+                 ghost_mask=ghost, n_iface=6 * (world - 1), dim=2)
+
+
 class ShardedChainEngine:
     """Rank r owns elements [r*n, (r+1)*n) of a world*n-element collinear truss (SURVEY.md §8d
-    inputs).  Same kernels and collectives as the general path; no global arrays are built."""
+    inputs).  Same kernels and collective as the general path; no global arrays are built."""
 
     def __init__(self, n_local: int, workload: str, rank: int, world: int, device):
         from .fem.model import FEMModel, Material
@@ -538,44 +503,30 @@ class ShardedChainEngine:
         from .nets import SimpleNN
         n = int(n_local)
         n_total = n * world
-        e0 = rank * n
-        x = (np.arange(n + 1, dtype=np.float64) + e0)
-        nodes_l = np.stack([x, np.zeros(n + 1)], axis=1)
-        el = np.stack([np.arange(n), np.arange(1, n + 1)], axis=1)
-        loads = np.zeros(2 * (n + 1))
-        if rank == world - 1:
-            loads[2 * n] = 1.0
-        fixed = list(2 * np.arange(n + 1) + 1)
-        if rank == 0:
+        shard = chain_shard(n, rank, world)
+        ng = shard.nodes_global
+        x = ng.astype(np.float64)
+        nodes_l = np.stack([x, np.zeros(ng.size)], axis=1)
+        el = shard.elements_local
+        loads = np.zeros(2 * ng.size)
+        tip = n_total - ng[0]
+        if 0 <= tip < ng.size:
+            loads[2 * tip] = 1.0
+        fixed = list(2 * np.arange(ng.size) + 1)
+        if ng[0] == 0:
             fixed = [0] + fixed
         fixed = np.array(sorted(fixed))
-        # shared nodes: global node r*n for r = 1..world-1  (local 0 of rank r, local n of rank r-1)
-        sd, ss = [], []
-        ghost = np.zeros(2 * (n + 1), dtype=bool)
-        if rank > 0:
-            sd += [0, 1]
-            ss += [2 * (rank - 1), 2 * (rank - 1) + 1]
-            ghost[0:2] = True                      # owned by rank-1
-        if rank < world - 1:
-            sd += [2 * n, 2 * n + 1]
-            ss += [2 * rank, 2 * rank + 1]
-        ie = ([0] if rank > 0 else []) + ([n - 1] if rank < world - 1 else [])   # elements at the shared nodes
-        shard = Shard(rank=rank, world=world, elem_lo=e0, elem_hi=e0 + n,
-                      nodes_global=np.arange(e0, e0 + n + 1), elements_local=el,
-                      shared_dofs=np.array(sd, dtype=np.int32), shared_slot=np.array(ss, dtype=np.int32),
-                      ghost_mask=ghost, n_iface=2 * (world - 1), dim=2,
-                      iface_elems=np.array(sorted(set(ie)), dtype=np.int32))
-        # measurements ux_i = x_i, uy_i = 0 at every global node >= 1 (owner adds the shared ones)
-        k = np.arange(n + 1)
-        keep = (k + e0 >= 1) & ~ghost[0::2]
+        # measurements ux_i = x_i, uy_i = 0 at every global node >= 1: the owner adds the data term
+        k = np.arange(ng.size)
+        keep = (ng >= 1) & ~shard.ghost_mask[0::2]
         kk = k[keep]
         md = np.stack([2 * kk, 2 * kk + 1], axis=1).reshape(-1)
         mv = np.stack([x[kk], np.zeros(kk.size)], axis=1).reshape(-1)
         hp = build_host_plan(nodes_l, el, loads, fixed, 2, mv, md)
         hp.dof_flags[shard.shared_dofs] |= _capi.PF_DOF_SHARED
-        hp.dof_flags[ghost] |= _capi.PF_DOF_GHOST
+        hp.dof_flags[shard.ghost_mask] |= _capi.PF_DOF_GHOST
         hp.n_meas = 2 * n_total
-        torch.manual_seed(0)                      # identical theta on every rank
+        torch.manual_seed(0)                      # identical theta on every rank (begin() broadcasts rank 0's anyway)
         widths = {"ex4": (20, 15, 10), "ex3": (20, None, None)}[workload]
         props = [1.0 if w is None else NNProperty(SimpleNN(2, w, 3), input_dim=3, scale=1.0)
                  for w in widths]
@@ -590,7 +541,7 @@ class ShardedChainEngine:
     def prepare(self):
         """Create the C driver's RCCL communicator (collective) ahead of the first iteration."""
         comm = rccl_comm(self.backend)
-        self.backend.driver_used = "c-rccl" if (comm is not None and self.backend.early_iface) else "python"
+        self.backend.driver_used = "c-rccl" if comm is not None else "python"
 
     def iterate(self, n):
         run_iterations(self.backend, n, bufs=self.bufs)

@@ -59,14 +59,13 @@ class HipEngine:
         self.adj_ptr, self.adj = t(hp.adj_ptr), t(hp.adj)
         self.f_ext, self.dof_flags, self.meas_val = t(hp.f_ext), t(hp.dof_flags), t(hp.meas_val)
         self.has_measurements = measured_disp is not None and measured_dofs is not None
-        # multi-GPU shard interface: (shared_dofs int32[], shared_slot int32[], n_iface[, iface_elems int32[]])
-        self.iface_elems, self.n_iface_elems = None, 0
+        # multi-GPU shard interface: (interface dofs int32[], their slots int32[], n_iface, (own_lo, own_hi))
+        self.own_range = (0, 0)
         if iface is not None:
             self.shared_dofs, self.shared_slot = t(np.asarray(iface[0], dtype=np.int32)), t(np.asarray(iface[1], dtype=np.int32))
             self.n_shared, self.n_iface = int(len(iface[0])), int(iface[2])
-            if len(iface) > 3 and iface[3] is not None and len(iface[3]):
-                self.iface_elems = t(np.asarray(iface[3], dtype=np.int32))
-                self.n_iface_elems = int(len(iface[3]))
+            if len(iface) > 3 and iface[3] is not None:
+                self.own_range = (int(iface[3][0]), int(iface[3][1]))
         else:
             self.shared_dofs = self.shared_slot = None
             self.n_shared = self.n_iface = 0
@@ -242,8 +241,7 @@ class HipEngine:
         P.shared_dofs = self.shared_dofs.data_ptr() if self.n_shared else None
         P.shared_slot = self.shared_slot.data_ptr() if self.n_shared else None
         P.n_shared, P.n_iface = self.n_shared, self.n_iface
-        P.iface_elems = self.iface_elems.data_ptr() if self.n_iface_elems else None
-        P.n_iface_elems = self.n_iface_elems
+        P.own_lo, P.own_hi = self.own_range
         P.prop_double = 1
         P.net_op = self.net_op.data_ptr() if self.wg_mode == _capi.PF_WG_MFMA32 else None
         P.op_off[0], P.op_off[1] = self._op_off

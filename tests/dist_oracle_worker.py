@@ -24,6 +24,9 @@ f32 = np.float32
 
 
 class OracleShardBackend(ShardBackend):
+    """The rank-local arithmetic by the numpy oracle on the local mesh (own + ghost elements) the PRODUCT's partition
+    produced; the phases, buffers and the collective are the product's (pinn_fem_amd.dist.run_iterations)."""
+
     def __init__(self, pb_global: orc.Problem, cfg: orc.SolverConfig, lam: float, rank: int, world: int):
         self.device = torch.device("cpu")
         dim = pb_global.dimension
@@ -34,11 +37,14 @@ class OracleShardBackend(ShardBackend):
         comp = np.arange(dim)
         self.dofs_global = (sh.nodes_global[:, None] * dim + comp[None, :]).reshape(-1)
         copy_net = lambda p: p.copy() if isinstance(p, orc.NetParams) else p
-        self.pb = orc.Problem(nodes=pb_global.nodes[sh.nodes_global], elements=sh.elements_local,
-                              loads=pb_global.loads[self.dofs_global], fixed_dofs=hp.fixed_dofs,
-                              dimension=dim, young=copy_net(pb_global.young),
-                              area=copy_net(pb_global.area), density=copy_net(pb_global.density))
-        self.geo = orc.element_geometry(self.pb)
+        mk = lambda elements: orc.Problem(nodes=pb_global.nodes[sh.nodes_global], elements=elements,
+                                          loads=pb_global.loads[self.dofs_global], fixed_dofs=hp.fixed_dofs,
+                                          dimension=dim, young=self.young, area=self.area, density=self.density)
+        self.young, self.area, self.density = (copy_net(pb_global.young), copy_net(pb_global.area),
+                                               copy_net(pb_global.density))
+        self.pb = mk(sh.elements_local)                                   # own + ghost: forces and residual
+        self.pb_own = mk(sh.elements_local[sh.own_lo:sh.own_hi])         # own only: gradients
+        self.geo, self.geo_own = orc.element_geometry(self.pb), orc.element_geometry(self.pb_own)
         self.cfg, self.lam = cfg, lam
         self.n_iface = sh.n_iface
         self.theta = self.pb.theta_list()
@@ -58,76 +64,72 @@ class OracleShardBackend(ShardBackend):
         self.m = float(hp.n_meas)
         self.history, self.done, self.converged, self.it = [], False, False, 0
 
-    # phase A (the product evaluates only the interface elements here; the values are the same)
-    def iface_forward(self, iface):
-        s, *_ = orc.element_stiffness(self.pb, self.geo, self.lam)
-        self.f_part = orc.internal_force(self.geo, s, self.u, self.hp.n_dofs)
-        iface.zero_()
-        iface[torch.from_numpy(self.shard.shared_slot.astype(np.int64))] = torch.from_numpy(
-            self.f_part[self.shard.shared_dofs])
+    def forward(self):
+        s, *_ = orc.element_stiffness(self.pb, self.geo, self.lam)        # all local elements
+        self.f_int = orc.internal_force(self.geo, s, self.u, self.hp.n_dofs)
 
-    def forward(self):        # phase B: nothing left to do for the CPU stand-in
+    def update_interior(self):  # folded into update_shared (same arithmetic, one Adam call)
         pass
 
-    def update_interior(self):  # phase D: folded into update_shared
-        pass
-
-    def _fix_residual(self, iface):
-        f = self.f_part.copy()
-        f[self.shard.shared_dofs] = iface.numpy()[self.shard.shared_slot]
-        r = (f - f32(self.lam) * self.hp.f_ext).astype(f32)
+    def backward(self, buf, u2):
+        r = (self.f_int - f32(self.lam) * self.hp.f_ext).astype(f32)       # complete on every node of an own element
         r[~self.free] = 0
         self.g_f = (f32(self.cfg.alpha_physics) * r).astype(f32)
         self.r2 = float(np.sum((r * r)[self.owned], dtype=f32))
         d = (self.hp.meas_val - self.u).astype(f32)
-        self.d = d
         self.d2 = float(np.sum((d * d)[self.meas & self.owned], dtype=f32)) if self.use_data else 0.0
-
-    def backward(self, iface, buf2):
-        self._fix_residual(iface)
-        gu, gt = orc.vjp_internal_force(self.pb, self.geo, self.u, self.lam, self.g_f)
+        gu, gt = orc.vjp_internal_force(self.pb_own, self.geo_own, self.u, self.lam, self.g_f)   # OWN elements only
         if self.use_data:
-            gd = (f32(self.cfg.alpha_data) / f32(self.m)) * (f32(2.0) * self.d)
-            gu[self.meas] += (-gd[self.meas]).astype(f32)
+            gd = (f32(self.cfg.alpha_data) / f32(self.m)) * (f32(2.0) * d)
+            gu[self.meas] += (-gd[self.meas]).astype(f32)               # the owner carries the MEASURED flag
         self.grad_u = gu
-        b = buf2.numpy()
+        b = buf.numpy()
         b[:] = 0
         b[self.shard.shared_slot] = gu[self.shard.shared_dofs]
         off = self.n_iface
         for g in gt:
             b[off:off + g.size] = g.reshape(-1)
             off += g.size
-        b[self.n_iface + self.n_theta_active:self.n_iface + self.n_theta_active + 2] = (self.r2, self.d2)
+        tail = self.n_iface + self.n_theta_active
+        b[tail:tail + 3] = (self.r2, self.d2, float(u2[0]))
 
-    def update_shared(self, buf2, sums3):
-        b = buf2.numpy()
-        self.grad_u[self.shard.shared_dofs] = b[self.shard.shared_slot]
-        self.opt_u.update([self.u], [self.grad_u])
-        grads, off = [], self.n_iface
-        for i, t in enumerate(self.theta):
-            if i < self.n_active_tensors:
-                grads.append(b[off:off + t.size].reshape(t.shape).copy())
-                off += t.size
-            else:
-                grads.append(None)
-        if self.theta:
-            self.opt_t.update(self.theta, grads)
-        self.u[~self.free] = 0
-        sums3.numpy()[2] = np.sum((self.u * self.u)[self.free & self.owned], dtype=f32)
+    def update_shared(self, buf, u2):
+        b = buf.numpy()
+        if not self.done:
+            self.grad_u[self.shard.shared_dofs] = b[self.shard.shared_slot]
+            self.opt_u.update([self.u], [self.grad_u])
+            grads, off = [], self.n_iface
+            for i, t in enumerate(self.theta):
+                if i < self.n_active_tensors:
+                    grads.append(b[off:off + t.size].reshape(t.shape).copy())
+                    off += t.size
+                else:
+                    grads.append(None)
+            if self.theta:
+                self.opt_t.update(self.theta, grads)
+            self.u[~self.free] = 0
+            u2.numpy()[0] = np.sum((self.u * self.u)[self.free & self.owned], dtype=f32)
+        tail = self.n_iface + self.n_theta_active
+        self._finalize(b[tail], b[tail + 1], b[tail + 2])
 
-    def finalize(self, r2d2, u2):
+    def _finalize(self, r2, d2, u2_prev):
         if self.done:
             return
-        r2, d2 = float(r2d2[0]), float(r2d2[1])
         lp = f32(0.5) * f32(r2)
         ld = f32(d2) / f32(self.m) if self.use_data else f32(0)
         loss = f32(self.cfg.alpha_physics) * lp + (f32(self.cfg.alpha_data) * ld if self.use_data else f32(0))
         rn = float(np.sqrt(f32(r2)))
+        if self.history:
+            self.history[-1]["u_norm"] = float(np.sqrt(f32(u2_prev)))     # the u-norm travels one iteration late
         self.history.append(dict(loss_total=float(loss), loss_physics=float(lp), loss_data=float(ld),
-                                 residual_norm=rn, u_norm=float(np.sqrt(f32(float(u2[0]))))))
+                                 residual_norm=rn, u_norm=0.0))
         if self.it > 10 and (rn < self.cfg.tolerance or float(loss) < self.cfg.tolerance):
             self.done = self.converged = True
         self.it += 1
+
+    def flush(self, u2_reduced):
+        if self.history:
+            self.history[-1]["u_norm"] = float(np.sqrt(f32(float(u2_reduced[0]))))
 
 
 def build_problem(kind):

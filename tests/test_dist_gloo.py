@@ -44,18 +44,47 @@ def test_sharded_matches_single_process(kind, world, port, tmp_path):
 
 
 def test_partition_properties():
-    from pinn_fem_amd.dist import element_ranges, partition_mesh
+    from pinn_fem_amd.dist import chain_shard, element_ranges, partition_mesh
     assert element_ranges(10, 3) == [(0, 4), (4, 7), (7, 10)]
     el = np.stack([np.arange(10), np.arange(1, 11)], axis=1)
     shards = [partition_mesh(el, 11, 2, r, 3) for r in range(3)]
-    assert all(s.n_iface == 4 for s in shards)            # nodes 4 and 7 are shared: 2 dofs each
-    assert list(shards[0].shared_slot) == [0, 1] and list(shards[1].shared_slot) == [0, 1, 2, 3]
-    assert list(shards[2].shared_slot) == [2, 3]
-    assert not shards[0].ghost_mask.any()                 # lowest sharing rank owns
-    assert shards[1].ghost_mask[:2].all() and not shards[1].ghost_mask[2:].any()
+    # nodes 4 and 7 are shared; interface = their element rings: nodes 3,4,5 and 6,7,8 -> 6 nodes x 2 dofs
+    assert all(s.n_iface == 12 for s in shards)
+    # ghost elements: rank 0 holds element 4, rank 1 elements 3 and 7, rank 2 element 6
+    assert list(shards[0].elems_global) == [0, 1, 2, 3, 4] and (shards[0].own_lo, shards[0].own_hi) == (0, 4)
+    assert list(shards[1].elems_global) == [3, 4, 5, 6, 7] and (shards[1].own_lo, shards[1].own_hi) == (1, 4)
+    assert list(shards[2].elems_global) == [6, 7, 8, 9] and (shards[2].own_lo, shards[2].own_hi) == (1, 4)
+    assert list(shards[0].nodes_global) == [0, 1, 2, 3, 4, 5]
+    assert list(shards[0].shared_slot) == [0, 1, 2, 3, 4, 5]                 # nodes 3, 4, 5
+    assert list(shards[1].shared_slot) == list(range(12))                    # nodes 3, 4, 5, 6, 7, 8
+    assert list(shards[2].shared_slot) == [6, 7, 8, 9, 10, 11]
+    # owner = lowest rank owning an incident element; everything else is flagged (incl. pure ghost nodes)
+    assert not shards[0].ghost_mask[:10].any() and shards[0].ghost_mask[10:].all()      # node 5: ghost on rank 0
+    assert shards[1].ghost_mask[:4].all() and not shards[1].ghost_mask[4:10].any() and shards[1].ghost_mask[10:].all()
     # every global node owned exactly once
     owned = np.concatenate([s.nodes_global[~s.ghost_mask[0::2]] for s in shards])
     assert sorted(owned) == list(range(11))
+    # the analytic chain shards of the bench are the same records
+    for world, n in ((3, 5), (2, 4), (4, 3)):
+        el = np.stack([np.arange(world * n), np.arange(1, world * n + 1)], axis=1)
+        for r in range(world):
+            a, b = partition_mesh(el, world * n + 1, 2, r, world), chain_shard(n, r, world)
+            for f in ("elem_lo", "elem_hi", "own_lo", "own_hi", "n_iface"):
+                assert getattr(a, f) == getattr(b, f), (f, world, n, r)
+            for f in ("elems_global", "nodes_global", "elements_local", "shared_dofs", "shared_slot", "ghost_mask"):
+                assert np.array_equal(getattr(a, f), getattr(b, f)), (f, world, n, r)
+    # an irregular mesh: every element incident to a node of an own element is local
+    rng = np.random.default_rng(0)
+    n_nodes, el = 60, []
+    for i in range(1, 60):
+        for j in rng.choice(i, size=min(i, 2), replace=False):
+            el.append((int(j), i))
+    el = np.array(el)
+    for r in range(4):
+        s = partition_mesh(el, n_nodes, 2, r, 4)
+        own_nodes = np.unique(el[s.elem_lo:s.elem_hi])
+        touching = np.flatnonzero(np.isin(el, own_nodes).any(axis=1))
+        assert set(touching) <= set(s.elems_global)
 
 
 def test_broadcast_theta_makes_replicas_identical(tmp_path):
