@@ -286,7 +286,10 @@ def main():
             ach = net_flops(w) * n_local / (slot_ms[dom] * 1e-3) / 1e12
             roof = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / F32_PEAK_TFLOPS, "traffic": None,
-                    "avg_launch_ms": float(slot_ms[dom])}
+                    "avg_launch_ms": float(slot_ms[dom]),
+                    "note": "algorithmic float32 flops (forward recompute + backward) against the dense f32 peak; the "
+                            "engine executes every f32-grade product as three f16 MFMAs (2-way split operands), and the "
+                            "kernel is bound by vector-ALU / transcendental issue, not by the matrix pipe (DESIGN.md §4)"}
         else:
             # share of the 144 B/eval the kernel is responsible for is not separable: price the
             # whole per-eval figure against this kernel's time (upper bound on its byte rate)
@@ -297,13 +300,13 @@ def main():
         # HBM traffic of the dominant kernel: rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in separate passes,
         # gfx950 correction applied) of this same command, committed under profiles/
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
                 tr = json.load(f)["kernels"]
-            key = {"net_backward_young": "k_net44_backward<2, 3, true>", "net_backward_area": "k_net44_backward<2, 3, false>",
+            key = {"net_backward_young": "k_net32_backward<2, 3, true>", "net_backward_area": "k_net32_backward<2, 3, false>",
                    "node_residual": "k_node_residual<2>", "node_gradu_adam": "k_node_gradu<2, true>"}.get(names[dom])
             if key in tr and n_local == 1_000_000 and args.workload == "ex4":
                 roof["traffic"] = tr[key]["hbm_bytes_corrected"]
-                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc, per launch)"
+                roof["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc, per launch)"
         except Exception:
             pass
         it_bytes = ALGO_BYTES_PER_EVAL * value / world / 1e9

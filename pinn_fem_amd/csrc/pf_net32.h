@@ -61,27 +61,35 @@ __device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned 
       const int hh = i >> 4, rr = i & 15, uu = 2 * rr + hh;
       bias[i] = uu < W ? (PF_N32_KA * PF_N32_KW) * bl[uu] : 0.f;
     }
-    _Float16* af = reinterpret_cast<_Float16*>(img + pf_n32_off_af(l));
-    _Float16* ab = reinterpret_cast<_Float16*>(img + pf_n32_off_ab(l));
-    for (int i = tid; i < 2 * 2 * 64 * 8; i += nt) {
-      const int j = i & 7, lane = (i >> 3) & 63, ks = (i >> 9) & 1, sp = i >> 10;
+    // operand entries: one thread builds the eight k-slots of one (split, k-step, lane) and stores them as 16 bytes
+    uint4* af = reinterpret_cast<uint4*>(img + pf_n32_off_af(l));
+    uint4* ab = reinterpret_cast<uint4*>(img + pf_n32_off_ab(l));
+    for (int i = tid; i < 2 * 2 * 64; i += nt) {
+      const int lane = i & 63, ks = (i >> 6) & 1, sp = i >> 7;
       const int rho = lane & 31, hh = lane >> 5;
       const int u_row = 2 * ((rho & 3) + 4 * (rho >> 3)) + ((rho >> 2) & 1);   // unit on tile row rho
-      const int u_k = 2 * (8 * ks + j) + hh;                                     // unit in k-slot j of half hh
-      float vf = 0.f, vb = 0.f;
-      if (u_row < W && u_k < W) {
-        vf = PF_N32_KW * Wl[u_row * W + u_k];     // z_l[u_row]   += W_l[u_row][u_k] a_{l-1}[u_k]
-        vb = PF_N32_KB * Wl[u_k * W + u_row];     // dh_{l-1}[u_row] += W_l[u_k][u_row] d_l[u_k]
+      unsigned short hf[8], hb[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int u_k = 2 * (8 * ks + j) + hh;                                   // unit in k-slot j of half hh
+        float vf = 0.f, vb = 0.f;
+        if (u_row < W && u_k < W) {
+          vf = PF_N32_KW * Wl[u_row * W + u_k];     // z_l[u_row]   += W_l[u_row][u_k] a_{l-1}[u_k]
+          vb = PF_N32_KB * Wl[u_k * W + u_row];     // dh_{l-1}[u_row] += W_l[u_k][u_row] d_l[u_k]
+        }
+        if (prec == 1) {
+          hf[j] = sp ? (unsigned short)0 : __builtin_bit_cast(unsigned short, (__bf16)vf);
+          hb[j] = sp ? (unsigned short)0 : __builtin_bit_cast(unsigned short, (__bf16)vb);
+        } else {
+          const _Float16 fh = (_Float16)vf, bh = (_Float16)vb;
+          hf[j] = __builtin_bit_cast(unsigned short, sp ? (_Float16)(vf - (float)fh) : fh);
+          hb[j] = __builtin_bit_cast(unsigned short, sp ? (_Float16)(vb - (float)bh) : bh);
+        }
       }
-      if (prec == 1) {
-        const __bf16 fb = (__bf16)vf, bb = (__bf16)vb;
-        reinterpret_cast<unsigned short*>(af)[i] = sp ? (unsigned short)0 : __builtin_bit_cast(unsigned short, fb);
-        reinterpret_cast<unsigned short*>(ab)[i] = sp ? (unsigned short)0 : __builtin_bit_cast(unsigned short, bb);
-      } else {
-        const _Float16 fh = (_Float16)vf, bh = (_Float16)vb;
-        af[i] = sp ? (_Float16)(vf - (float)fh) : fh;
-        ab[i] = sp ? (_Float16)(vb - (float)bh) : bh;
-      }
+      af[i] = make_uint4(hf[0] | (unsigned)hf[1] << 16, hf[2] | (unsigned)hf[3] << 16, hf[4] | (unsigned)hf[5] << 16,
+                         hf[6] | (unsigned)hf[7] << 16);
+      ab[i] = make_uint4(hb[0] | (unsigned)hb[1] << 16, hb[2] | (unsigned)hb[3] << 16, hb[4] | (unsigned)hb[5] << 16,
+                         hb[6] | (unsigned)hb[7] << 16);
     }
   }
   // bound for the backward scaling: v_L[j] = |wo[j]|, v_{l-1}[k] = sum_j |W_l[j][k]| v_l[j];

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes as
+"""profiles/r0N_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate passes as
 MI355X_MICROARCH.md prescribes): per-launch averages per kernel, FETCH_SIZE doubled (gfx950 counts 64 B per
 128-B request), bytes = fetch*2 + write.   python tools/pmc_traffic.py <fetch_csv> <write_csv> <out_json> <note>"""
 import collections, csv, json, re, sys
@@ -26,12 +26,9 @@ def main():
     for k in sorted(fetch):
         fr, wr = fetch[k], write.get(k, 0.0)
         kernels[k] = {"launches": nf[k], "fetch_raw": fr, "write_raw": wr}
-    cal = [v["fetch_raw"] for k, v in kernels.items() if k.startswith("k_net44_forward")]
-    unit = 1.0
-    if cal:
-        # 10^6 elements x 8 B of centroids = 8.0e6 B algorithmic read; raw*2*unit should match it
-        guess = 8.0e6 / (2.0 * cal[0])
-        unit = 1024.0 if 700 < guess < 1500 else (1000.0 if 1.0 < guess < 700 else 1.0)
+    # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB on this stack (calibrated in round 1 on the forward kernel's
+    # 8.0 MB of centroids: profiles/r01_traffic.json, counter_unit_bytes 1024)
+    unit = 1024.0
     total = 0.0
     for k, v in kernels.items():
         v["fetch_bytes_raw"] = v.pop("fetch_raw") * unit
