@@ -39,7 +39,6 @@ def _sources():
     units += [(f"pf_net32b_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}", "-DPF_PREC=1", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
               for r in reversed(NR_BUCKETS)]
     units += [(f"pf_net_{w}.o", "pf_net.hip", [f"-DPF_HP={w}"]) for w in WIDTHS]
-    units += [(f"pf_net16_{w}.o", "pf_net16.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]) for w in WIDTHS]
     return units
 
 

@@ -96,8 +96,6 @@ static int check_problem(const pf_problem* p) {
   }                                                               \
   return fail(PF_ERR_UNSUPPORTED, "net width outside 1..32");
 
-static int net_forward16(const pf_problem* p, int which, hipStream_t s) { PF_WIDTH_SWITCH(pf_launch_net16_forward_) }
-
 // MFMA32 engine: one translation unit per register bucket
 #define PF_NR_SWITCH(PREFIX)                                      \
   switch (pf_net32_bucket(p->net[which].width)) {                 \
@@ -120,11 +118,8 @@ static int net_forward(const pf_problem* p, int which, hipStream_t s, int write_
   return net_forward_impl(&q, which, s);
 }
 static int net_forward_impl(const pf_problem* p, int which, hipStream_t s) {
-  // PF_FWD_F16=1: the split-f16 forward kernel (pf_net16.hip) in place of the 4x4x1 f32 one
-  static const bool fwd16 = getenv("PF_FWD_F16") && atoi(getenv("PF_FWD_F16")) != 0;
   if (p->wg_mode == PF_WG_MFMA32 && p->mlp_dtype == PF_MLP_BF16) { PF_NR_SWITCH(pf_launch_net32b_forward_) }
   if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_forward_) }
-  if (p->wg_mode == PF_WG_MFMA44 && fwd16) return net_forward16(p, which, s);
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_forward_) }
   PF_WIDTH_SWITCH(pf_launch_net_forward_)
 }

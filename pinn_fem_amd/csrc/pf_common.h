@@ -241,8 +241,7 @@ int pf_node_blocks(int n_nodes);
   int pf_launch_net_backward_##HP(const pf_problem* p, int which, hipStream_t s);          \
   int pf_launch_net44_forward_##HP(const pf_problem* p, int which, hipStream_t s);        \
   int pf_launch_net44_backward_##HP(const pf_problem* p, int which, hipStream_t s);       \
-  int pf_launch_net44_backward_gea_##HP(const pf_problem* p, int which, hipStream_t s);   \
-  int pf_launch_net16_forward_##HP(const pf_problem* p, int which, hipStream_t s);
+  int pf_launch_net44_backward_gea_##HP(const pf_problem* p, int which, hipStream_t s);
 PF_DECL_NET_LAUNCHERS(4)
 PF_DECL_NET_LAUNCHERS(8)
 PF_DECL_NET_LAUNCHERS(12)

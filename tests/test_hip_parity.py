@@ -811,37 +811,6 @@ def test_newton_raphson_1d_bar_vs_oracle():
     assert abs(res.history[-1]["max_strain"] - ref.history[-1]["max_strain"]) < 1e-6 * ref.history[-1]["max_strain"]
 
 
-def test_split_f16_forward_engine_matches_oracle(tmp_path):
-    """The experimental forward kernel on the f16 matrix pipe with 2-way split operands (pf_net16.hip, enabled by
-    PF_FWD_F16=1; off by default: parity-green but not yet faster than the 4x4x1 f32 kernel) against the oracle's
-    property evaluation: E and A at 5000 elements of the synthetic chain within 2e-6 relative (the f32 engines sit
-    at the same level)."""
-    import subprocess
-    import sys
-    from helpers import ROOT
-    code = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')
-from test_hip_parity import _chain_model, _engine
-from helpers import orc
-model, pb, mv, md = _chain_model(5000, widths=(20, 15, 10), h=0.7)
-eng = _engine(model, mv, md, 2, 0)
-eng.eval_properties(0.6)
-n = 5000
-E, A = eng.prop_e[:n].cpu().numpy(), eng.prop_a[:n].cpu().numpy()
-geo = orc.element_geometry(pb)
-x = orc.nn_inputs(geo, 0.6)
-Eo = orc.property_forward(pb.young, x)[0]
-Ao = orc.property_forward(pb.area, x)[0]
-rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
-print('REL', rel(E, Eo), rel(A, Ao))
-assert rel(E, Eo) < 2e-6 and rel(A, Ao) < 2e-6
-""" % (ROOT, ROOT)
-    env = dict(os.environ, PF_FWD_F16="1", PINNFEM_QUIET="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-
-
 def test_cli_one_dimensional_list_format_json(tmp_path):
     """`generic.py` on a dimension-1 problem in the list format (nodes [[x], ...], elements [[i, j], ...], explicit
     fixed_dofs; examples/json/generic.py:155-192): classical FEM (auto -> Newton-Raphson) and a PINN-GD run with an

@@ -2,7 +2,7 @@
 """Parity summary against the reference goldens (tests/golden/run_*.json, seed 0): for every example
 run the HIP path (and the numpy oracle) end to end and report iteration counts, max relative errors of
 displacements, reactions and of the identified E, A and E*A at the element centroids.
-    python tools/parity_summary.py > profiles/r01_parity_summary.json   (needs a GPU)"""
+    python tools/parity_summary.py > profiles/r0N_parity_summary.json   (needs a GPU)"""
 import json
 import os
 import sys
@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("PINNFEM_QUIET", "1")
+
+_OUT = os.fdopen(os.dup(1), "w")      # the JSON goes to the real stdout; the solvers' progress prints go to stderr
+os.dup2(2, 1)
 
 from helpers import example_problem, load_run, orc, product_example, rel_err  # noqa: E402
 
@@ -84,7 +87,7 @@ def main():
             row["identified_at_centroids_max_rel_err"] = {
                 who: {k: float(max(v)) for k, v in d.items()} for who, d in errs.items()}
         rows.append(row)
-    print(json.dumps(rows, indent=1))
+    _OUT.write(json.dumps(rows, indent=1) + "\n")
 
 
 if __name__ == "__main__":
