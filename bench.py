@@ -247,6 +247,14 @@ def main():
         run_events = lambda n: eng.iterate_timed(n)
         graph_count = lambda: 0
 
+    # (1) K steps launched eagerly with a HIP event before every kernel on the launch stream: the per-kernel
+    # durations of the roofline (not part of `value`).  Run first, so that the timed region below starts on a chip
+    # that has already left its idle clocks; the W warm-up steps still come right before the timed K.
+    t1 = time.perf_counter()
+    slot_ms = run_events(args.steps)
+    torch.cuda.synchronize(dev)
+    dt_events = time.perf_counter() - t1
+    # (2) W untimed warm-up steps, (3) EXACTLY K timed steps between barrier + synchronize
     run_warm(n_warm)
     graphs_before = graph_count()
     torch.cuda.synchronize(dev)
@@ -254,7 +262,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    run_timed(args.steps)                    # EXACTLY K steps: the product path (hipGraph replay)
+    run_timed(args.steps)                    # the product path (hipGraph replay)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -265,14 +273,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     st = eng.state()
-    assert st.iter == n_warm + args.steps, (st.iter, n_warm + args.steps)
+    assert st.iter == n_warm + 2 * args.steps, (st.iter, n_warm + 2 * args.steps)
     assert graph_count() == graphs_before, "a hipGraph was captured inside the timed region"
-    # the same K steps once more, launched eagerly with a HIP event before every kernel on the launch
-    # stream: per-kernel durations for the roofline (not part of `value`)
-    t1 = time.perf_counter()
-    slot_ms = run_events(args.steps)
-    torch.cuda.synchronize(dev)
-    dt_events = time.perf_counter() - t1
 
     if rank == 0:
         total_elems = n_local * world

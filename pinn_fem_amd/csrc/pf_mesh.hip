@@ -218,12 +218,12 @@ __device__ __forceinline__ void theta_stage2(const pf_problem& P, int fuse_adam,
 }
 
 // MFMA32 engine: rebuild the split-f16 operand images of the enabled nets from `th` (the flat active
-// parameters: LDS copy of the values just written, or global theta).  Every thread of the block; has barriers.
-__device__ __forceinline__ void pack_net_ops(const pf_problem& P, const float* th, float* scratch64) {
+// parameters: LDS copy of the values just written, or global theta).  Every thread of the block; no barriers.
+__device__ __forceinline__ void pack_net_ops(const pf_problem& P, const float* th) {
   if (P.wg_mode != PF_WG_MFMA32 || !P.net_op) return;
   for (int k = 0; k < 2; ++k) {
     if (!P.net[k].enabled) continue;
-    pf_n32_pack(P.net[k], th + P.net[k].theta_off, reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]), scratch64,
+    pf_n32_pack(P.net[k], th + P.net[k].theta_off, reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]),
                 P.mlp_dtype);
   }
 }
@@ -231,19 +231,17 @@ __device__ __forceinline__ void pack_net_ops(const pf_problem& P, const float* t
 __global__ __launch_bounds__(1024) void k_theta_stage2(pf_problem P, int fuse_adam) {
   if (P.state->done) return;
   extern __shared__ float new_theta[];   // n_theta_active floats (MFMA32 engine only)
-  __shared__ float scratch[64];
   const bool ops = P.wg_mode == PF_WG_MFMA32 && fuse_adam;
   theta_stage2(P, fuse_adam, ops ? new_theta : nullptr);
   if (ops) {
     __syncthreads();
-    pack_net_ops(P, new_theta, scratch);
+    pack_net_ops(P, new_theta);
   }
 }
 
 __global__ __launch_bounds__(256) void k_pack_theta(pf_problem P) {
-  __shared__ float scratch[64];
   for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) P.theta_pad[P.pad_index[q]] = P.theta[q];
-  pack_net_ops(P, P.theta, scratch);
+  pack_net_ops(P, P.theta);
 }
 
 // ---- parameter update + monitors / history / stop test / next Adam scalars ------------------------
@@ -261,12 +259,11 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
   extern __shared__ float new_theta[];  // n_theta_active floats
   __shared__ double dred[16];
   __shared__ float wnorm[16];
-  __shared__ float scratch[64];
   if (with_theta) {
     theta_stage2(P, mode == 0, new_theta);
     if (mode == 0) {
       __syncthreads();
-      pack_net_ops(P, new_theta, scratch);
+      pack_net_ops(P, new_theta);
     }
   }
   double a = 0.0, b = 0.0, c = 0.0;
@@ -389,7 +386,6 @@ __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node
   PF_NO_CONTRACT
   if (P.state->done) return;   // sums3 keeps the previous (final) value: finalize ignores it once done
   __shared__ double dred[16];
-  __shared__ float scratch[64];
   extern __shared__ float new_theta_dyn[];     // n_theta_active floats with the MFMA32 engine, else none
   float* new_theta = P.wg_mode == PF_WG_MFMA32 ? new_theta_dyn : nullptr;
   const pf_mesh& M = P.mesh;
@@ -415,7 +411,7 @@ __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node
   }
   if (new_theta) {
     __syncthreads();
-    pack_net_ops(P, new_theta, scratch);
+    pack_net_ops(P, new_theta);
   }
   double c = 0.0;
   {

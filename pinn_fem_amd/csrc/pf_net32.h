@@ -31,9 +31,9 @@ __host__ __device__ constexpr int pf_n32_bytes(int n_hidden) { return pf_n32_off
 // header: float[0] = bound on max_l 4^(L-l) |d_l| / |g_z| (the backward's power-of-two scaling), float[1..3] spare
 
 // Build the image of net `which` from its parameters `th` (torch parameters() order: W1 [w][in], b1, (Wl [w][w],
-// bl)*, Wo [1][w], bo).  Called by every thread of one block; `scratch` = 64 floats of LDS.  Contains barriers.
+// bl)*, Wo [1][w], bo).  Called by every thread of one block (a multiple of 64 threads); no barriers, reads only th.
 // prec 0: split f16 (hi, lo); prec 1: plain bf16 in the hi slots (round to nearest), lo slots zero.
-__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, float* scratch, int prec) {
+__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, int prec) {
   const int W = net.width, L = net.n_hidden, IN = net.in_dim;
   const int o_b1 = W * IN, o_h = W * IN + W, per = W * W + W, o_wo = o_h + (L - 1) * per, o_bo = o_wo + W;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -93,36 +93,33 @@ __device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned 
     }
   }
   // bound for the backward scaling: v_L[j] = |wo[j]|, v_{l-1}[k] = sum_j |W_l[j][k]| v_l[j];
-  // bound = max_l 4^(L-l) max_k v_l[k]  (|d_l| <= |g_z| v_l since 4 t = 1 - a^2 <= 1)
-  float* va = scratch;
-  float* vb2 = scratch + 32;
-  if (tid < 32) va[tid] = tid < W ? fabsf(th[o_wo + tid]) : 0.f;
-  __syncthreads();
-  float bound = 0.f;   // (thread 0's copy is the one stored)
-  float grow = 1.f;
-  for (int l = L; l >= 1; --l) {
-    if (tid == 0) {
-      float m = 0.f;
-      for (int k = 0; k < W; ++k) m = fmaxf(m, va[k]);
+  // bound = max_l 4^(L-l) max_k v_l[k]  (|d_l| <= |g_z| v_l since 4 t = 1 - a^2 <= 1).
+  // One wave (the block's last, which has the least operand work), v in registers: lane k holds v[k].
+  if ((tid >> 6) == ((nt - 1) >> 6)) {
+    const int lane = tid & 63;
+    float v = lane < W ? fabsf(th[o_wo + lane]) : 0.f;
+    float bound = 0.f, grow = 1.f;
+    for (int l = L; l >= 1; --l) {
+      float m = v;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
       bound = fmaxf(bound, grow * m);
-    }
-    grow *= 4.f;
-    if (l >= 2) {
-      const float* Wl = th + o_h + (l - 2) * per;
-      if (tid < 32) {
+      grow *= 4.f;
+      if (l >= 2) {
+        const float* Wl = th + o_h + (l - 2) * per;
         float a = 0.f;
-        if (tid < W)
-          for (int j = 0; j < W; ++j) a += fabsf(Wl[j * W + tid]) * va[j];
-        vb2[tid] = a;
+#pragma unroll 4
+        for (int j = 0; j < W; ++j) {
+          const float w = lane < W ? fabsf(Wl[j * W + lane]) : 0.f;
+          a += w * __shfl(v, j);
+        }
+        v = a;
       }
-      __syncthreads();
-      float* t = va; va = vb2; vb2 = t;
+    }
+    if (lane == 0) {
+      float* hdr = reinterpret_cast<float*>(img);
+      hdr[0] = bound > 0.f ? bound : 1.f;
+      hdr[1] = hdr[2] = hdr[3] = 0.f;
     }
   }
-  if (tid == 0) {
-    float* hdr = reinterpret_cast<float*>(img);
-    hdr[0] = bound > 0.f ? bound : 1.f;
-    hdr[1] = hdr[2] = hdr[3] = 0.f;
-  }
-  __syncthreads();
 }
