@@ -461,27 +461,40 @@ constexpr int SP_STRIDE = COMPACT ? 1792 : 2304;      // hi image -> lo image
 constexpr int C1_OFF = 1152;                          // chunk 0 -> chunk 1
 constexpr int REGION = COMPACT ? 3584 : 4608;
 constexpr int WAVE_SCRATCH = 2 * REGION;
-constexpr int CONST_BYTES = 1536;                     // zero block at +192, bias block at +960 (both = 192 mod 256)
-// waves per block (one block per CU): 12 (three per SIMD, 168 registers) where the kernel fits that budget without
-// spilling — measured with -Rpass-analysis: one hidden layer, or two without the fused element adjoint — else 8.
-// A spill reload inside the task loop is followed by s_waitcnt vmcnt(0), which also waits for the NEXT task's
-// prefetched gathers: the spilling 12-wave variant ran slower than the 8-wave one.
+// Constant blocks (512 B each, all = 192 mod 256) sit at the SAME distances from each other as the images they
+// complete: zero block Z at +192 (A hi), Z + SP_STRIDE (A lo), Z + REGION = bias block (B hi), Z + REGION + SP_STRIDE
+// (B lo).  Every lane therefore reads all four operands at ONE per-lane base plus compile-time offsets.
+constexpr int CONST_BYTES = COMPACT ? 6144 : 256;
+// waves per block (one block per CU): as many as the kernel's registers allow without spilling (checked in the
+// compiler's asm: ScratchSize 0 for every bucket) — 16 (four per SIMD, 128 registers) with one hidden layer, 12 (three
+// per SIMD, 168 registers) with two, else 8.  The MLP kernels are bound by the per-wave issue rate (one vector
+// instruction per ~4 cycles and wave), so waves per SIMD is what buys throughput.  A spill reload inside
+// the task loop is followed by s_waitcnt vmcnt(0), which also waits for the NEXT task's prefetched gathers: a spilling
+// 12-wave variant ran slower than the 8-wave one — hence the single per-lane LDS base (operand_base / write_base)
+// and the SGPR-held block-uniform scalars.
 template <int L, bool GEA>
-constexpr int bw_threads() { return (COMPACT && (L == 1 || (L == 2 && !GEA))) ? 768 : 512; }
-constexpr int BW_MAX_THREADS = 768;
+constexpr int bw_threads() { return !COMPACT ? 512 : (L == 1 ? 1024 : (L == 2 && !(GEA && NR > 10) ? 768 : 512)); }
 
-// lane's pairs (hi or lo) of registers 0..15 -> the region's split `sp`.  bias_col: wide layout only, B side hi image:
-// the lane's register 15 carries the bias column's KA (lower half-wave)
-__device__ __forceinline__ void write_rows(unsigned char* region, int sp, int lane, const unsigned (&pk)[NPK],
-                                           bool bias_col = false) {
+// lane's pairs (hi or lo) of registers 0..15 -> split `sp` of the region at byte offset `reg` of the wave scratch.
+// wr0 / wr1: the lane's write positions of chunk 0 / chunk 1 in the A region's hi image (write_base).  bias_col: wide
+// layout only, B side hi image: the lane's register 15 carries the bias column's KA (lower half-wave)
+struct WriteBase { unsigned char* c0; unsigned char* c1; };
+__device__ __forceinline__ WriteBase write_base(unsigned char* scratch, int lane) {
   const int hs = lane >> 5, e = lane & 31;
-  unsigned char* p = region + sp * SP_STRIDE;
-  *reinterpret_cast<u32x4*>(p + hs * 576 + e * 16) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+  WriteBase w;
+  w.c0 = scratch + hs * 576 + e * 16;
+  w.c1 = COMPACT ? scratch + C1_OFF + 64 * (e >> 2) + 32 * hs + 8 * (e & 3) : scratch + C1_OFF + hs * 576 + e * 16;
+  return w;
+}
+template <int REG, int SP>
+__device__ __forceinline__ void write_rows(const WriteBase& wb, int lane, const unsigned (&pk)[NPK], bool bias_col = false) {
+  constexpr int OFF = REG + SP * SP_STRIDE;
+  *reinterpret_cast<u32x4*>(wb.c0 + OFF) = u32x4{pk[0], pk[1], pk[2], pk[3]};
   if constexpr (!COMPACT) {
-    const unsigned k7 = pk[7] | ((bias_col && hs == 0) ? (BF ? 0x45000000u : 0x68000000u) : 0u);   // 2048.0 (bf16 / f16) in the high half
-    *reinterpret_cast<u32x4*>(p + C1_OFF + hs * 576 + e * 16) = u32x4{pk[4], pk[5], pk[6], k7};
+    const unsigned k7 = pk[7] | ((bias_col && (lane >> 5) == 0) ? (BF ? 0x45000000u : 0x68000000u) : 0u);   // 2048.0 (bf16 / f16) in the high half
+    *reinterpret_cast<u32x4*>(wb.c1 + OFF) = u32x4{pk[4], pk[5], pk[6], k7};
   } else if constexpr (NR > 8) {
-    *reinterpret_cast<u32x2*>(p + C1_OFF + 64 * (e >> 2) + 32 * hs + 8 * (e & 3)) = u32x2{pk[4], pk[5]};
+    *reinterpret_cast<u32x2*>(wb.c1 + OFF) = u32x2{pk[4], pk[5]};
   }
 }
 
@@ -489,23 +502,23 @@ __device__ __forceinline__ void write_rows(unsigned char* region, int sp, int la
 // reads the 4x16 block rows (elements) e0..e0+3, columns 16*(g&1)..+15; lane 4q+p of the group supplies the address of
 // row q, columns 4p..4p+3.  The element part 16*e0 = 256*ks + 64*half (+128*(lane>>5), folded in here) is the same for
 // every lane, so the reads of a tile use immediate offsets.
-__device__ __forceinline__ const unsigned char* operand_base(const unsigned char* region, int sp, int lane,
-                                                             const unsigned char* p3block) {
+__device__ __forceinline__ const unsigned char* operand_base(const unsigned char* scratch, int lane,
+                                                             const unsigned char* zblock) {
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
   const int hsrc = g & 1, hl = g >> 1;
-  const unsigned char* img = region + sp * SP_STRIDE;
   const unsigned char* a;
   if constexpr (COMPACT) {
-    a = p < 2 ? img + hsrc * 576 + q * 16 + 8 * (p & 1)
-              : (p == 2 ? img + C1_OFF + 32 * hsrc + 8 * q : p3block + 32 * hsrc + 8 * q);
+    a = p < 2 ? scratch + hsrc * 576 + q * 16 + 8 * (p & 1)
+              : (p == 2 ? scratch + C1_OFF + 32 * hsrc + 8 * q : zblock + 32 * hsrc + 8 * q);
   } else {
-    a = img + (p >> 1) * C1_OFF + hsrc * 576 + q * 16 + 8 * (p & 1);
+    a = scratch + (p >> 1) * C1_OFF + hsrc * 576 + q * 16 + 8 * (p & 1);
   }
   return a + 128 * hl;
 }
+template <int OFF>
 __device__ __forceinline__ h8 read_operand(const unsigned char* base, int ks) {
-  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + 256 * ks));
-  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + 256 * ks + 64));
+  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + OFF + 256 * ks));
+  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + OFF + 256 * ks + 64));
   typedef short s8v __attribute__((ext_vector_type(8)));
   return __builtin_bit_cast(h8, s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
@@ -567,12 +580,10 @@ template <int L, int IN>
 __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ img, unsigned char* scratch, int lane,
                                               const TileAct<L, true>& A, float gs /* g_z S of the column's element */,
                                               const unsigned (&xhi)[NPK], const unsigned (&xlo)[NPK],
-                                              f32x16 (&T)[L],
-                                              const unsigned char* const (&rd)[4] /* A hi, A lo, B hi, B lo */,
-                                              const unsigned char* rdBhi_in /* B hi with the zero block */, int dbg = 0) {
+                                              f32x16 (&T)[L], const WriteBase& wb,
+                                              const unsigned char* rd /* operand_base: A hi; A lo, B hi, B lo at fixed offsets */,
+                                              int dbg = 0) {
   const int h = lane >> 5;
-  unsigned char* regA = scratch;
-  unsigned char* regB = scratch + REGION;
   // d_L[r] = (4 wo[2r+h] g_z S) t_L[r]
   float d[2 * NPR];
   {
@@ -603,27 +614,32 @@ __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ 
     }
     // gradient tile of layer LL: rows d_LL through LDS; columns a_{LL-1} (LL >= 2) or the inputs (LL == 1)
     if (!(dbg & 1)) {
-      write_rows(regA, 0, lane, dhi);
-      if constexpr (!BF) write_rows(regA, 1, lane, dlo);
+      write_rows<0, 0>(wb, lane, dhi);
+      if constexpr (!BF) write_rows<0, 1>(wb, lane, dlo);
       if constexpr (LL >= 2) {
-        write_rows(regB, 0, lane, A.hi[LL - 2], true);
-        if constexpr (!BF) write_rows(regB, 1, lane, A.lo[LL - 2]);
+        write_rows<REGION, 0>(wb, lane, A.hi[LL - 2], true);
+        if constexpr (!BF) write_rows<REGION, 1>(wb, lane, A.lo[LL - 2]);
       } else {
         // inputs of the element: registers 0..3 of the lower half-wave's slot (columns 0..3) of the B region
+        // (for h == 0 the chunk-0 position IS lane * 16)
         if (h == 0) {
-          *reinterpret_cast<u32x2*>(regB + lane * 16) = u32x2{xhi[0], xhi[1]};
-          if constexpr (!BF) *reinterpret_cast<u32x2*>(regB + SP_STRIDE + lane * 16) = u32x2{xlo[0], xlo[1]};
+          *reinterpret_cast<u32x2*>(wb.c0 + REGION) = u32x2{xhi[0], xhi[1]};
+          if constexpr (!BF) *reinterpret_cast<u32x2*>(wb.c0 + REGION + SP_STRIDE) = u32x2{xlo[0], xlo[1]};
         }
       }
       // the wave's own LDS writes are visible to its own later reads (in-order); tell the compiler only
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // inputs tile (LL == 1): its B hi image has no bias column (the element's inputs carry their own 1.0), so the
+      // lanes that read column quad 12..15 take the ZERO block (their base, as it is) instead of the bias block
+      const unsigned char* rdb = rd;
+      if constexpr (LL == 1 && COMPACT) rdb = ((lane & 3) == 3) ? rd - REGION : rd;
       sfor<0, 2>([&](auto ks) {
         constexpr int S = ks;
-        const h8 ahi = read_operand(rd[0], S), bhi = read_operand(LL >= 2 ? rd[2] : rdBhi_in, S);
+        const h8 ahi = read_operand<0>(rd, S), bhi = read_operand<REGION>(rdb, S);
         h8 alo = ahi, blo = bhi;     // (unused with plain bf16 operands)
-        if constexpr (!BF) { alo = read_operand(rd[1], S); blo = read_operand(rd[3], S); }
+        if constexpr (!BF) { alo = read_operand<SP_STRIDE>(rd, S); blo = read_operand<REGION + SP_STRIDE>(rd, S); }
         T[LL - 1] = mfma3(T[LL - 1], ahi, alo, bhi, blo);
       });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -652,17 +668,17 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
   const int h = lane >> 5;
   copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), IMG);
   constexpr int IMGPAD = (IMG + 255) & ~255;
-  unsigned char* cst = smem + IMGPAD;                  // constant blocks: zeros at +192, bias column block at +960
+  unsigned char* cst = smem + IMGPAD;                  // constant blocks (see CONST_BYTES)
   unsigned char* scratch = smem + IMGPAD + CONST_BYTES + wv * WAVE_SCRATCH;
   for (int i = threadIdx.x; i < CONST_BYTES / 4; i += blockDim.x) reinterpret_cast<unsigned*>(cst)[i] = 0u;
   for (int i = lane; i < WAVE_SCRATCH / 16; i += 64) reinterpret_cast<uint4*>(scratch)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   // bias block: [element/4][half-wave][element%4] x (registers 12..15 as f16): KA in register 15 of the lower half-wave
   if (threadIdx.x < 32)
-    *reinterpret_cast<unsigned short*>(cst + 960 + 64 * (threadIdx.x >> 2) + 8 * (threadIdx.x & 3) + 6) = BF ? 0x4500 : 0x6800;   // 2048.0
-  const unsigned char* rd[4] = {operand_base(scratch, 0, lane, cst + 192), operand_base(scratch, 1, lane, cst + 192),
-                                operand_base(scratch + REGION, 0, lane, cst + 960), operand_base(scratch + REGION, 1, lane, cst + 192)};
-  const unsigned char* rdBhi_in = operand_base(scratch + REGION, 0, lane, cst + 192);   // inputs image: no bias column
+    if constexpr (COMPACT)
+      *reinterpret_cast<unsigned short*>(cst + 192 + REGION + 64 * (threadIdx.x >> 2) + 8 * (threadIdx.x & 3) + 6) = BF ? 0x4500 : 0x6800;   // 2048.0
+  const unsigned char* rd = operand_base(scratch, lane, cst + 192);
+  const WriteBase wb = write_base(scratch, lane);
 
   const int stride = gridDim.x * waves * 64;
   int base = (blockIdx.x * waves + wv) * 64;
@@ -672,9 +688,10 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
   if (P.state->done != 0 || n <= 0) return;      // block-uniform
   task_fetch_b<IN, GEA>(nxt, P);
 
-  const float bound = reinterpret_cast<const float*>(smem)[0];
-  const float kx = __builtin_ldexpf(1.0f, P.coord_exp);
-  const float inv_scale = 1.0f / net.scale;
+  // block-uniform scalars: keep them in SGPRs (the kernel runs at its register budget)
+  const float bound = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, reinterpret_cast<const float*>(smem)[0])));
+  const float kx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_ldexpf(1.0f, P.coord_exp))));
+  const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / net.scale)));
   f32x16 T[L];          // sum over this wave's tasks of S * (tile products); S = Srun, a power of two that only falls
   sfor<0, L>([&](auto l) { constexpr int LL = l; T[LL] = zero16(); });
   float Srun = 0.f;     // 0: not chosen yet
@@ -742,8 +759,9 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
       sfor<2, NPK>([&](auto q) { constexpr int Q = q; xhi[Q] = 0u; xlo[Q] = 0u; });
       split_pair(PF_N32_KL * xt[0], kx * xt[1], xhi[0], xlo[0]);
       split_pair(IN == 3 ? kx * xt[2] : 1.0f, IN == 3 ? 1.0f : 0.f, xhi[1], xlo[1]);
-      if (!(dbg & 2)) backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, rd, rdBhi_in, dbg);
+      // (before backward_tile: a'_L is dead there, ten registers less at the kernel's pressure peak)
       sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = fmaf(gt, A.aL[R], go[R]); });
+      if (!(dbg & 2)) backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, wb, rd, dbg);
     });
     gbo += gz;
   }
