@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 4
+#define PF_ABI_VERSION 5
 
 /* error codes */
 #define PF_OK 0
@@ -154,7 +154,8 @@ typedef struct pf_problem {
    * shared node), sorted by global id, so the own elements are the local range [own_lo, own_hi); 0, 0 on one GPU.
    * Gradients (MLP backward, grad_u) are taken over the own elements only. */
   int32_t own_lo, own_hi;
-  int32_t _pad3;
+  int32_t part_half;        /* 0|1: which half of the residual's block partial sums this launch writes / the stand-alone
+                               pf_finalize reads (0 unless the caller pipelines finalize into the next residual) */
   /* != 0: prop_e and prop_a hold 2*n_elems floats; the iteration graph then alternates between the two
    * halves, so the forwards of iteration t+1 need not wait for the last reader of iteration t's properties */
   int32_t prop_double;

@@ -7,7 +7,7 @@
 #include "pf_net32.h"
 
 // launchers from pf_mesh.hip
-int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s);
+int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s, int fin_prev = 0);
 int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s);
 int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared = 0);
 int pf_launch_shard_pack(const pf_problem* p, float* buf2, const float* u2_local, hipStream_t s);
@@ -15,7 +15,7 @@ int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* u2_loc
 int pf_launch_shard_flush(const pf_problem* p, const float* u2, hipStream_t s);
 int pf_launch_theta_reduce(const pf_problem* p, int fuse_adam, hipStream_t s);
 int pf_launch_pack_theta(const pf_problem* p, hipStream_t s);
-int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s);
+int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s, int tn_ready = 0);
 int pf_launch_theta_stage1(const pf_problem* p, hipStream_t s);
 int pf_launch_theta_stage2(const pf_problem* p, int fuse_adam, hipStream_t s);
 int pf_launch_reset(const pf_problem* p, hipStream_t s);
@@ -131,7 +131,14 @@ static int net_backward(const pf_problem* p, int which, hipStream_t s) {
   PF_WIDTH_SWITCH(pf_launch_net_backward_)
 }
 
-// backward that also computes and stores the element adjoint g_ea (MFMA44 engine only)
+// Is the element adjoint (dL/d(EA) per element) computed inside the first net's backward kernel?
+static bool fuse_gea_for(const pf_problem* p) {
+  static const int knob = getenv("PF_FUSE_GEA") ? atoi(getenv("PF_FUSE_GEA")) : -1;   // experiment knob
+  if (p->wg_mode == PF_WG_MFMA44) return true;
+  if (p->wg_mode == PF_WG_MFMA32) return knob < 0 ? true : knob != 0;
+  return false;
+}
+// backward that also computes and stores the element adjoint g_ea
 static int net_backward_gea(const pf_problem* p, int which, hipStream_t s) {
   if (p->wg_mode == PF_WG_MFMA32 && p->mlp_dtype == PF_MLP_BF16) { PF_NR_SWITCH(pf_launch_net32b_backward_gea_) }
   if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_backward_gea_) }
@@ -306,7 +313,7 @@ static int enqueue_iteration(const pf_problem* p, int fuse_adam, int finalize_mo
   if (p->net[1].enabled) PF_TRY(net_forward(p, 1, s), "net_forward");
   PF_MARK(K_RESIDUAL);
   PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
-  const bool fuse_gea = any_net && (p->wg_mode == PF_WG_MFMA44 || p->wg_mode == PF_WG_MFMA32);
+  const bool fuse_gea = any_net && fuse_gea_for(p);
   const int first = p->net[0].enabled ? 0 : 1;
   PF_MARK(K_ADJOINT);
   if (any_net && !fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
@@ -332,6 +339,7 @@ static int check_gd(const pf_problem* p) {
   if (rc) return rc;
   if (!p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null Adam moments for u");
   if (p->n_theta_active > 0 && (!p->m_t || !p->v_t)) return fail(PF_ERR_ARG, "null Adam moments for theta");
+  if (p->n_tensors > 64) return fail(PF_ERR_UNSUPPORTED, "more than 64 parameter tensors");   // PF_MAX_TENSORS (pf_mesh.hip)
   return PF_OK;
 }
 
@@ -349,7 +357,8 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
 // Iterations as a dependency graph instead of a chain (only meaningful while capturing a hipGraph).
 // What each kernel of iteration t really waits for:
 //   forward E, A        theta_pad(t)  [stage 2 of t-1];  nothing reads prop_e/prop_a any more  [gradu of t-1]
-//   node_residual       forwards, u(t) [gradu of t-1], the block partials are free           [finalize of t-1]
+//   node_residual       forwards, u(t) [gradu of t-1]; its block 0 = finalize(t-1): stage 2 of t-1, gradu of t-1, and the
+//                       OTHER half of the residual's partial sums (part_half)
 //   backward #1 (+gea)  g_f; it is the last reader of u(t)
 //   gradu + Adam(u)     g_f, the properties, backward #1 done; the Adam scalars                [finalize of t-1]
 //   backward #2, theta stage 1, stage 2 + Adam(theta)   in this order after backward #1
@@ -387,31 +396,25 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     }
     return PF_OK;
   }
-  const bool fuse_gea = (p->wg_mode == PF_WG_MFMA44 || p->wg_mode == PF_WG_MFMA32);
+  const bool fuse_gea = fuse_gea_for(p);
   const int first = p->net[0].enabled ? 0 : 1;
   // The runtime keeps the FIRST-created child of a node on its parent's hardware queue and moves later
-  // children to other queues; a dependency whose last parent sits on another queue costs ~10 us (kernel trace).
-  // So the nodes are created in the order that keeps the critical chain (forwards, residual, backwards,
-  // theta) on one queue: finalize(i-1) is created AFTER the forwards of iteration i (PF_GRAPH_ORDER=0: the
-  // older order, finalize first; experiment knob).
-  static const bool late_fin = !(getenv("PF_GRAPH_ORDER") && atoi(getenv("PF_GRAPH_ORDER")) == 0);
+  // children to other queues; every fork or join on the main chain costs ~5 us (kernel trace).  So the nodes are
+  // created in the order that keeps the critical chain (forwards, residual, backwards, theta) on one queue, and
+  // the bookkeeping kernel has NO node of its own: finalize(i-1) runs as block 0 of node_residual(i)
+  // (pf_mesh.hip: k_node_residual, fin_prev) from the other half of the residual's partial sums
+  // (pf_problem.part_half), finalize of the graph's last iteration as a stand-alone launch at its end.
   static const bool pp_knob = !(getenv("PF_GRAPH_PINGPONG") && atoi(getenv("PF_GRAPH_PINGPONG")) == 0);
-  const bool pingpong = p->prop_double != 0 && pp_knob && late_fin;
-  auto capture_finalize = [&](int i) -> int {   // branch B: behind stage 2 (e[2]) and gradu (e[1]) of iteration i
-    hipEvent_t* e = c.ev + PF_CAP_EV * i;
-    if (hipStreamWaitEvent(c.b, e[2], 0) != hipSuccess || hipStreamWaitEvent(c.b, e[1], 0) != hipSuccess)
-      return fail(PF_ERR_HIP, "graph edge failed");
-    PF_TRY(pf_launch_finalize(p, 0, 0, c.b), "finalize");
-    if (hipEventRecord(e[3], c.b) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    return PF_OK;
-  };
+  const bool pingpong = p->prop_double != 0 && pp_knob;
+  const int tn_ready = p->wg_mode == PF_WG_MFMA32 ? 1 : 0;   // k_theta_stage2 leaves the theta-norm monitor in the state
+  static const bool fin_branch = getenv("PF_GRAPH_FIN") && !strcmp(getenv("PF_GRAPH_FIN"), "branch");   // experiment knob
   for (int i = 0; i < iters; ++i) {
     hipEvent_t* e = c.ev + PF_CAP_EV * i;
     hipEvent_t* ep = c.ev + PF_CAP_EV * (i - 1);
     // Property buffers ping-pong between iterations (prop_double), so the forwards of iteration i do not wait
     // for gradu(i-1), the last reader of the other half: the main chain then has ONE incoming edge from another
-    // queue per iteration (finalize(i-1) -> residual(i), which also covers gradu(i-1) -> u) and it has ~25 us of
-    // slack.  Without the second half the forwards wait for gradu(i-1) (an 11 us hole in the kernel trace).
+    // queue per iteration (gradu(i-1) -> residual(i): u, and the u-norm partials finalize(i-1) reads there).
+    // Without the second half the forwards wait for gradu(i-1) (an 11 us hole in the kernel trace).
     pf_problem q = *p;
     const pf_problem* p = &q;   // (shadows the argument for the rest of this iteration)
     if (pingpong && (i & 1)) {
@@ -419,18 +422,25 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
       q.prop_a += q.mesh.n_elems;
       if (q.elem_s) q.elem_s += q.mesh.n_elems;
     }
+    q.part_half = i & 1;
     if (i > 0 && !pingpong && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
     // (the two forwards run one after the other: side by side on two branches they measured slower, 0.195 vs
     // 0.190 ms per iteration with the f32 engine — the same issue pipe — and the second one writes elem_s from both)
     for (int k = 0; k < 2; ++k)
       if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
-    if (i > 0 && late_fin) {
-      int rc = capture_finalize(i - 1);
-      if (rc != PF_OK) return rc;
+    // residual(i) reads u(i) [gradu(i-1)]; its block 0 is finalize(i-1): behind stage 2 (this chain) and gradu(i-1)
+    if (i > 0 && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    if (fin_branch && i > 0) {
+      // the older form (PF_GRAPH_FIN=branch): finalize(i-1) as a node of its own on a second side branch, beside the forwards
+      if (hipStreamWaitEvent(c.b, ep[2], 0) != hipSuccess || hipStreamWaitEvent(c.b, ep[1], 0) != hipSuccess)
+        return fail(PF_ERR_HIP, "graph edge failed");
+      pf_problem qq = q;
+      qq.part_half = (i - 1) & 1;
+      PF_TRY(pf_launch_finalize(&qq, 0, 0, c.b, tn_ready), "finalize");
+      if (hipEventRecord(ep[3], c.b) != hipSuccess || hipStreamWaitEvent(s, ep[3], 0) != hipSuccess)
+        return fail(PF_ERR_HIP, "graph edge failed");
     }
-    // finalize(i-1) reads the block partials node_residual rewrites, and writes the Adam scalars
-    if (i > 0 && hipStreamWaitEvent(s, ep[3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
+    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, i > 0 && !fin_branch ? (tn_ready ? 2 : 1) : 0), "node_residual");
     if (!fuse_gea) {
       PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
       if (hipEventRecord(e[0], s) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
@@ -447,17 +457,14 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     if (hipStreamWaitEvent(c.a, e[0], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
     PF_TRY(pf_launch_node_gradu(p, 1, c.a), "node_gradu");
     if (hipEventRecord(e[1], c.a) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    if (!late_fin) {
-      int rc = capture_finalize(i);
-      if (rc != PF_OK) return rc;
-    }
   }
-  if (late_fin) {
-    int rc = capture_finalize(iters - 1);
-    if (rc != PF_OK) return rc;
+  // finalize of the last iteration: behind stage 2 (this chain) and the last gradu
+  if (hipStreamWaitEvent(s, c.ev[PF_CAP_EV * (iters - 1) + 1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
+  {
+    pf_problem q = *p;
+    q.part_half = (iters - 1) & 1;
+    PF_TRY(pf_launch_finalize(&q, 0, 0, s, tn_ready), "finalize");
   }
-  // join: finalize of the last iteration is behind everything else
-  if (hipStreamWaitEvent(s, c.ev[PF_CAP_EV * (iters - 1) + 3], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
   return PF_OK;
 }
 
@@ -607,7 +614,7 @@ int pf_shard_backward(const pf_problem* p, float* buf, const float* u2_local, vo
   PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
   if (any_net) {
     const pf_problem q = own_view(p);
-    const bool fuse_gea = q.wg_mode == PF_WG_MFMA44 || q.wg_mode == PF_WG_MFMA32;
+    const bool fuse_gea = fuse_gea_for(&q);
     const int first = q.net[0].enabled ? 0 : 1;
     if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(&q, s), "elem_adjoint");
     for (int k = 0; k < 2; ++k)

@@ -8,12 +8,15 @@
 #define PF_WAVE 64
 
 // ---- partial-sum workspace layout (floats) -------------------------------------------
-// [0, 3*PF_NODE_SLOTS)            : per-node-block scalar partials  (sum r^2 | sum d^2 | sum u_free^2)
-// [3*PF_NODE_SLOTS, ...)          : per-block padded weight-gradient rows [n_part_blocks][pad_total]
-#define PF_PART_R2 0
-#define PF_PART_D2 (PF_NODE_SLOTS)
+// [0, 5*PF_NODE_SLOTS)            : per-node-block scalar partials: sum r^2 | sum d^2 (half 0) | sum u_free^2 |
+//                                   sum r^2 | sum d^2 (half 1).  The residual's sums exist twice (pf_problem.part_half)
+//                                   because the bookkeeping of iteration t runs INSIDE the residual launch of t+1
+//                                   (iteration graph, pf_api.hip), which is already writing the other half.
+// [5*PF_NODE_SLOTS, ...)          : per-block padded weight-gradient rows [n_part_blocks][pad_total]
+#define PF_PART_R2H(h) ((h) ? 3 * PF_NODE_SLOTS : 0)
+#define PF_PART_D2H(h) ((h) ? 4 * PF_NODE_SLOTS : PF_NODE_SLOTS)
 #define PF_PART_U2 (2 * PF_NODE_SLOTS)
-#define PF_PART_WG (3 * PF_NODE_SLOTS)
+#define PF_PART_WG (5 * PF_NODE_SLOTS)
 // after the [n_part_blocks][pad_total] rows: [PF_RG][pad_total] second-level partial rows
 #define PF_RG 16
 

@@ -56,15 +56,26 @@ __device__ __forceinline__ void gather_kv(const pf_problem& P, const float* __re
 // Multi-GPU: the local mesh carries the ghost elements of every shared node, so f_int is complete on every node of
 // an own element; a dof flagged PF_DOF_GHOST (owned by another rank, or a pure ghost node whose f_int is partial and
 // never used) is left out of the sums.
+__device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int with_theta, const float* __restrict__ ext_rd,
+                              const float* __restrict__ ext_u2, int u2_lag, int half, float* new_theta, int tn_ready);
+
+// fin_prev (1, or 2 = with tn_ready): block 0 does the bookkeeping of the PREVIOUS iteration (finalize_body: monitors, history row, stop test,
+// next Adam scalars) from the other half of the residual sums while the remaining blocks work on this iteration's
+// nodes — the single-block, latency-bound finalize then costs nothing and needs no branch of its own in the graph.
 template <int DIM>
 __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_residual(pf_problem P, float* f_int_out,
-                                                                    int compute_loss) {
+                                                                    int compute_loss, int fin_prev) {
+  if (fin_prev && blockIdx.x == 0) {
+    finalize_body(P, (int)gridDim.x - 1, 0, 0, nullptr, nullptr, 0, P.part_half ^ 1, nullptr, fin_prev == 2);
+    return;
+  }
   if (P.state->done) return;
   __shared__ float red[16];
   const pf_mesh& M = P.mesh;
+  const int fp = fin_prev ? 1 : 0;     // (fin_prev is 1 or 2: ONE extra block either way)
+  const int bid = (int)blockIdx.x - fp, nblk = (int)gridDim.x - fp;
   float sum_r2 = 0.f, sum_d2 = 0.f;
-  for (int node = blockIdx.x * blockDim.x + threadIdx.x; node < M.n_nodes;
-       node += gridDim.x * blockDim.x) {
+  for (int node = bid * blockDim.x + threadIdx.x; node < M.n_nodes; node += nblk * blockDim.x) {
     float f[2];
     gather_kv<DIM>(P, P.u, node, f);
 #pragma unroll
@@ -91,8 +102,8 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_residual(pf_problem P,
   const float t0 = pf_block_sum(sum_r2, red);
   const float t1 = pf_block_sum(sum_d2, red);
   if (threadIdx.x == 0) {
-    P.partials[PF_PART_R2 + blockIdx.x] = t0;
-    P.partials[PF_PART_D2 + blockIdx.x] = t1;
+    P.partials[PF_PART_R2H(P.part_half) + bid] = t0;
+    P.partials[PF_PART_D2H(P.part_half) + bid] = t1;
   }
 }
 
@@ -228,14 +239,50 @@ __device__ __forceinline__ void pack_net_ops(const pf_problem& P, const float* t
   }
 }
 
+// theta_norm = sum_k ||theta_k||_2 over ALL parameter tensors (density included), solver.py:319.  The calling wave
+// writes the norms of tensors first, first + step, ... to tnorm[]; each is one wave's lane-strided sum, and the caller
+// adds them in tensor order, so the value does not depend on how many waves share the work.
+#define PF_MAX_TENSORS 64
+__device__ __forceinline__ void tensor_norms(const pf_problem& P, const float* new_theta, int first, int step,
+                                             float* tnorm) {
+  const int lane = threadIdx.x & 63;
+  for (int t = first; t < P.n_tensors; t += step) {
+    const int lo = P.tensor_off[t], hi = P.tensor_off[t + 1];
+    float s = 0.f;
+    for (int i = lo + lane; i < hi; i += 64) {
+      const float x = (new_theta && i < P.n_theta_active) ? new_theta[i] : P.theta[i];
+      s += x * x;
+    }
+    const float v = sqrtf(pf_wave_sum(s));
+    if (lane == 0) tnorm[t] = v;
+  }
+}
+__device__ __forceinline__ double tensor_norm_total(const pf_problem& P, const float* tnorm) {
+  double tn = 0.0;
+  for (int t = 0; t < P.n_tensors; ++t) tn += (double)tnorm[t];
+  return tn;
+}
+
+// MFMA32 engine (iteration graph): besides the update and the operand images, the block's otherwise idle waves compute
+// the iteration's theta-norm monitor from the LDS copy of the new parameters (state->theta_norm), so that the
+// bookkeeping (finalize_body with tn_ready) has no dependent chain of global loads left.
 __global__ __launch_bounds__(1024) void k_theta_stage2(pf_problem P, int fuse_adam) {
   if (P.state->done) return;
   extern __shared__ float new_theta[];   // n_theta_active floats (MFMA32 engine only)
+  __shared__ float tnorm[PF_MAX_TENSORS];
   const bool ops = P.wg_mode == PF_WG_MFMA32 && fuse_adam;
   theta_stage2(P, fuse_adam, ops ? new_theta : nullptr);
   if (ops) {
     __syncthreads();
-    pack_net_ops(P, new_theta);
+    pack_net_ops(P, new_theta);           // operand entries: waves 0..3, scaling bound: the last wave
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (nw >= 8) {
+      if (wv >= 4 && wv < nw - 1) tensor_norms(P, new_theta, wv - 4, nw - 5, tnorm);
+    } else {
+      tensor_norms(P, new_theta, wv, nw, tnorm);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) P.state->theta_norm = (float)tensor_norm_total(P, tnorm);
   }
 }
 
@@ -251,25 +298,41 @@ __global__ __launch_bounds__(256) void k_pack_theta(pf_problem P) {
 // this rank's block partials (which already belong to the next iteration when this runs).
 // u2_lag (multi-GPU): ext_u2 is the sum of the PREVIOUS iteration (it travelled on this iteration's all-reduce):
 // it completes the previous history row; this iteration's u_norm is filled in by the next call (or by k_shard_flush).
-__global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, int mode, int with_theta,
-                                                   const float* __restrict__ ext_rd,
-                                                   const float* __restrict__ ext_u2, int u2_lag) {
+// `half`: which half of the residual's partial sums to read.  One block of PF_FIN_THREADS threads (the fixed-order
+// sums below depend on the block size: the stand-alone kernel and the block inside k_node_residual use the same).
+#define PF_FIN_THREADS PF_NODE_THREADS
+// tn_ready: state->theta_norm already holds this iteration's value (k_theta_stage2).
+__device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int with_theta, const float* __restrict__ ext_rd,
+                              const float* __restrict__ ext_u2, int u2_lag, int half, float* new_theta, int tn_ready) {
+  // Latency-bound (one block, a handful of dependent global round trips — and inside k_node_residual every one of them
+  // competes with 2047 memory-bound blocks): all loads are issued up front, the stop flag is only acted on at the end,
+  // and the two double-precision pow() of the next Adam scalars run on a second wave beside the sums.
   pf_state* S = P.state;
-  if (S->done) return;
-  extern __shared__ float new_theta[];  // n_theta_active floats
+  const int done0 = S->done;
   __shared__ double dred[16];
-  __shared__ float wnorm[16];
+  __shared__ double adam_bc[2];
+  __shared__ float tnorm[PF_MAX_TENSORS];
   if (with_theta) {
+    if (done0) return;
     theta_stage2(P, mode == 0, new_theta);
     if (mode == 0) {
       __syncthreads();
       pack_net_ops(P, new_theta);
     }
   }
+  const int it = S->iter;  // 0-based index of the iteration just completed
+  const float tn_state = S->theta_norm;
+  if (mode == 0 && threadIdx.x == 64) {
+    // Adam scalars of step t = it+2, in double like torch's Python floats
+    const double t = (double)(it + 2);
+    adam_bc[0] = 1.0 - pow(P.beta1, t);
+    adam_bc[1] = 1.0 - pow(P.beta2, t);
+  }
   double a = 0.0, b = 0.0, c = 0.0;
+#pragma unroll 4
   for (int i = threadIdx.x; i < nb_node; i += blockDim.x) {
-    a += (double)P.partials[PF_PART_R2 + i];
-    b += (double)P.partials[PF_PART_D2 + i];
+    a += (double)P.partials[PF_PART_R2H(half) + i];
+    b += (double)P.partials[PF_PART_D2H(half) + i];
     if (mode == 0) c += (double)P.partials[PF_PART_U2 + i];
   }
   float sum_r2 = (float)pf_block_sum_d(a, dred);
@@ -289,27 +352,17 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
     loss = P.alpha_physics * loss_p;                                    // :283
   }
   const float rn = sqrtf(sum_r2);                                       // torch.norm :306
-  // theta_norm = sum_k ||theta_k||_2 over ALL parameter tensors (density included) :319
-  // wave w owns tensors w, w+16, ...; fixed order -> reproducible
   double tn = 0.0;
   if (mode == 0 && P.n_tensors > 0) {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float wsum = 0.f;
-    for (int t = wv; t < P.n_tensors; t += 16) {
-      const int lo = P.tensor_off[t], hi = P.tensor_off[t + 1];
-      float s = 0.f;
-      for (int i = lo + lane; i < hi; i += 64) {
-        const float x = (with_theta && i < P.n_theta_active) ? new_theta[i] : P.theta[i];
-        s += x * x;
-      }
-      wsum += sqrtf(pf_wave_sum(s));
+    if (tn_ready) {
+      tn = (double)tn_state;
+    } else {
+      tensor_norms(P, with_theta ? new_theta : nullptr, threadIdx.x >> 6, blockDim.x >> 6, tnorm);
+      __syncthreads();
+      if (threadIdx.x == 0) tn = tensor_norm_total(P, tnorm);
     }
-    if (lane == 0) wnorm[wv] = wsum;
-    __syncthreads();
-    if (threadIdx.x == 0)
-      for (int w = 0; w < 16; ++w) tn += (double)wnorm[w];
   }
-  if (threadIdx.x != 0) return;
+  if (threadIdx.x != 0 || done0) return;   // (after the last barrier)
   S->loss_total = loss;
   S->loss_physics = loss_p;
   S->loss_data = loss_d;
@@ -318,7 +371,6 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
   const float un = sqrtf(sum_u2);                                       // :304
   S->u_norm = un;
   S->theta_norm = (float)tn;
-  const int it = S->iter;  // 0-based index of the iteration just completed
   if (P.hist && it < P.max_iter) {
     float* h = P.hist + (size_t)it * PF_HIST_COLS;
     h[0] = loss; h[1] = loss_p; h[2] = loss_d; h[3] = u2_lag ? 0.f : un; h[4] = rn; h[5] = (float)tn;
@@ -332,12 +384,17 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
     }
   }
   if (it + 1 >= P.max_iter) S->done = 1;
-  // Adam scalars of step t = it+2, in double like torch's Python floats
-  const double t = (double)(it + 2);
-  const double bc1 = 1.0 - pow(P.beta1, t), bc2 = 1.0 - pow(P.beta2, t);
+  const double bc1 = adam_bc[0], bc2 = adam_bc[1];
   S->step_size_u = (float)((double)P.lr_u / bc1);
   S->step_size_t = (float)((double)P.lr_t / bc1);
   S->bc2_sqrt = (float)sqrt(bc2);
+}
+
+__global__ __launch_bounds__(PF_FIN_THREADS) void k_finalize(pf_problem P, int nb_node, int mode, int with_theta,
+                                                             const float* __restrict__ ext_rd,
+                                                             const float* __restrict__ ext_u2, int u2_lag, int tn_ready) {
+  extern __shared__ float new_theta[];  // n_theta_active floats
+  finalize_body(P, nb_node, mode, with_theta, ext_rd, ext_u2, u2_lag, P.part_half, new_theta, tn_ready);
 }
 
 // ---- multi-GPU shard interface -------------------------------------------------------------------
@@ -368,8 +425,8 @@ __global__ __launch_bounds__(1024) void k_shard_pack(pf_problem P, int nb_node, 
   }
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nb_node; i += blockDim.x) {
-    a += (double)P.partials[PF_PART_R2 + i];
-    b += (double)P.partials[PF_PART_D2 + i];
+    a += (double)P.partials[PF_PART_R2H(P.part_half) + i];
+    b += (double)P.partials[PF_PART_D2H(P.part_half) + i];
   }
   const double ta = pf_block_sum_d(a, dred), tb = pf_block_sum_d(b, dred);
   if (threadIdx.x == 0) {
@@ -550,12 +607,12 @@ int pf_node_blocks(int n_nodes) {
   return nb;
 }
 
-int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s) {
-  const int nb = pf_node_blocks(p->mesh.n_nodes);
+int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s, int fin_prev) {
+  const int nb = pf_node_blocks(p->mesh.n_nodes) + (fin_prev ? 1 : 0);
   if (p->mesh.dim == 2)
-    hipLaunchKernelGGL(k_node_residual<2>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss);
+    hipLaunchKernelGGL(k_node_residual<2>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss, fin_prev);
   else
-    hipLaunchKernelGGL(k_node_residual<1>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss);
+    hipLaunchKernelGGL(k_node_residual<1>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, f_int_out, compute_loss, fin_prev);
   return PF_CHECK_LAUNCH();
 }
 
@@ -610,7 +667,7 @@ int pf_launch_pack_theta(const pf_problem* p, hipStream_t s) {
 }
 
 // with_theta: also run theta stage 2 (+Adam in mode 0) inside the finalize block
-int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s) {
+int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_t s, int tn_ready) {
   const int nb_node = pf_node_blocks(p->mesh.n_nodes);
   const int wt = with_theta && p->n_theta_active > 0;
   const size_t lds = wt ? (size_t)p->n_theta_active * sizeof(float) : 0;
@@ -618,8 +675,8 @@ int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_
     pf_set_error("too many trainable parameters for the fused finalize kernel");
     return PF_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), lds, s, *p, nb_node, mode, wt,
-                     (const float*)nullptr, (const float*)nullptr, 0);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PF_FIN_THREADS), lds, s, *p, nb_node, mode, wt,
+                     (const float*)nullptr, (const float*)nullptr, 0, tn_ready);
   return PF_CHECK_LAUNCH();
 }
 
@@ -667,7 +724,7 @@ int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* u2_loc
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, int u2_lag, hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(1024), 0, s, *p, 0, 0, 0, rd, u2, u2_lag);
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PF_FIN_THREADS), 0, s, *p, 0, 0, 0, rd, u2, u2_lag, 0);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_shard_flush(const pf_problem* p, const float* u2, hipStream_t s) {

@@ -167,7 +167,9 @@ class HipEngine:
         self.g_ea = torch.zeros(ne, **f32)
         self.grad_u = torch.zeros(nd, **f32)
         self.grad_theta = torch.zeros(max(self.n_theta, 1), **f32)
-        self.partials = torch.zeros(3 * _capi.PF_NODE_SLOTS + (self.n_part_blocks + 16) * max(self.pad_total, 1), **f32)
+        size_probe = PfProblem()                      # the library owns the workspace layout: ask it for the size
+        size_probe.n_part_blocks, size_probe.pad_total = self.n_part_blocks, max(self.pad_total, 1)
+        self.partials = torch.zeros(int(self.lib.pf_partials_count(C.byref(size_probe))), **f32)
         self.state_t = torch.zeros(C.sizeof(PfState) // 4, dtype=torch.int32, device=dev)
         self.hist = torch.zeros(1, **f32)
         self.hist_rows = 0
