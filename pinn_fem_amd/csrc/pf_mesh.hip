@@ -63,7 +63,7 @@ __device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int wi
 // next Adam scalars) from the other half of the residual sums while the remaining blocks work on this iteration's
 // nodes — the single-block, latency-bound finalize then costs nothing and needs no branch of its own in the graph.
 template <int DIM>
-__global__ __launch_bounds__(PF_NODE_THREADS) void k_node_residual(pf_problem P, float* f_int_out,
+__global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void k_node_residual(pf_problem P, float* f_int_out,
                                                                     int compute_loss, int fin_prev) {
   if (fin_prev && blockIdx.x == 0) {
     finalize_body(P, (int)gridDim.x - 1, 0, 0, nullptr, nullptr, 0, P.part_half ^ 1, nullptr, fin_prev == 2);
@@ -298,8 +298,7 @@ __global__ __launch_bounds__(256) void k_pack_theta(pf_problem P) {
 // this rank's block partials (which already belong to the next iteration when this runs).
 // u2_lag (multi-GPU): ext_u2 is the sum of the PREVIOUS iteration (it travelled on this iteration's all-reduce):
 // it completes the previous history row; this iteration's u_norm is filled in by the next call (or by k_shard_flush).
-// `half`: which half of the residual's partial sums to read.  One block of PF_FIN_THREADS threads (the fixed-order
-// sums below depend on the block size: the stand-alone kernel and the block inside k_node_residual use the same).
+// `half`: which half of the residual's partial sums to read.  One block of PF_FIN_THREADS threads or more.
 #define PF_FIN_THREADS PF_NODE_THREADS
 // tn_ready: state->theta_norm already holds this iteration's value (k_theta_stage2).
 __device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int with_theta, const float* __restrict__ ext_rd,
@@ -328,12 +327,16 @@ __device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int wi
     adam_bc[0] = 1.0 - pow(P.beta1, t);
     adam_bc[1] = 1.0 - pow(P.beta2, t);
   }
+  // fixed summation order whatever the block size (256 inside k_node_residual, 1024 stand-alone with theta stage 2):
+  // PF_FIN_THREADS strided partial sums, then the waves in order (further waves add exact zeros)
   double a = 0.0, b = 0.0, c = 0.0;
+  if (threadIdx.x < PF_FIN_THREADS) {
 #pragma unroll 4
-  for (int i = threadIdx.x; i < nb_node; i += blockDim.x) {
-    a += (double)P.partials[PF_PART_R2H(half) + i];
-    b += (double)P.partials[PF_PART_D2H(half) + i];
-    if (mode == 0) c += (double)P.partials[PF_PART_U2 + i];
+    for (int i = threadIdx.x; i < nb_node; i += PF_FIN_THREADS) {
+      a += (double)P.partials[PF_PART_R2H(half) + i];
+      b += (double)P.partials[PF_PART_D2H(half) + i];
+      if (mode == 0) c += (double)P.partials[PF_PART_U2 + i];
+    }
   }
   float sum_r2 = (float)pf_block_sum_d(a, dred);
   float sum_d2 = (float)pf_block_sum_d(b, dred);
@@ -390,7 +393,7 @@ __device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int wi
   S->bc2_sqrt = (float)sqrt(bc2);
 }
 
-__global__ __launch_bounds__(PF_FIN_THREADS) void k_finalize(pf_problem P, int nb_node, int mode, int with_theta,
+__global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, int mode, int with_theta,
                                                              const float* __restrict__ ext_rd,
                                                              const float* __restrict__ ext_u2, int u2_lag, int tn_ready) {
   extern __shared__ float new_theta[];  // n_theta_active floats
@@ -675,7 +678,7 @@ int pf_launch_finalize(const pf_problem* p, int mode, int with_theta, hipStream_
     pf_set_error("too many trainable parameters for the fused finalize kernel");
     return PF_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PF_FIN_THREADS), lds, s, *p, nb_node, mode, wt,
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(wt ? 1024 : PF_FIN_THREADS), lds, s, *p, nb_node, mode, wt,
                      (const float*)nullptr, (const float*)nullptr, 0, tn_ready);
   return PF_CHECK_LAUNCH();
 }
