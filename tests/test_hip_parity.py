@@ -1004,3 +1004,45 @@ def test_api_pinn_gd_matches_oracle_restatement():
     # evaluations drift apart by a few steps of lr * u_scale = 2e-5 over 300 iterations (measured: 4e-6 absolute on one
     # dof = 2.3e-4 of max |u|, every other dof to 1e-7); bound: two such steps relative to max |u| ~ 0.018
     assert rel_err(got["u_final"], ref["u_final"]) < 2e-3
+
+
+def _bench_line(args, env_extra=None, timeout=900):
+    import subprocess
+    import sys
+    from helpers import ROOT
+    env = dict(os.environ, PINNFEM_QUIET="1", **(env_extra or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line (the driver's contract)
+    return json.loads(lines[0])
+
+
+def test_bench_contract_single_gpu():
+    """`bench.py` at a small size: one JSON line with the driver's keys, the roofline and cpu_baseline objects, no
+    graph capture inside the timed region (asserted inside bench.py), K timed steps."""
+    d = _bench_line(["--gpus", "1", "--steps", "20", "--warmup", "5", "--elems", "50000", "--cpu-sample", "20000",
+                     "--cpu-iters", "2", "--no-also"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["graph_captured_before_timing"] is True and "workload" in d["config"]
+    assert abs(d["value"] - 50000 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
+    rf, cb = d["roofline"], d["cpu_baseline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["rows"]) >= 4
+
+
+def test_bench_two_rank_rehearsal():
+    """`bench.py --gpus 2` without a launcher starts its own two ranks; here both on this one GPU over gloo
+    (PINNFEM_BENCH_ONE_GPU=1: a rehearsal of the N>1 code path, not a multi-GPU number): the sharded driver runs, the
+    line reports the whole job (2 x elems per step) and which shard driver ran."""
+    d = _bench_line(["--gpus", "2", "--steps", "10", "--warmup", "2", "--elems", "30000", "--no-cpu-baseline", "--no-also"],
+                    {"PINNFEM_BENCH_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "REHEARSAL" in d["data"]
+    assert d["config"]["elements_total"] == 60000 and "shard_driver" in d["config"]
+    assert abs(d["value"] - 60000 * 10 / (d["ms_per_step"] * 10e-3)) < 1e-6 * d["value"]
