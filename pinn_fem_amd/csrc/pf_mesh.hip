@@ -178,7 +178,7 @@ __global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P, in
 // stage 1: [nb_rows][pad_total] -> [PF_RG][pad_total]; grid (ceil(pad_total/64), PF_RG), 256 threads =
 // 64 columns x 4 row lanes, every thread a short strided row sum, then a fixed-order LDS combine.
 __global__ __launch_bounds__(256) void k_theta_stage1(pf_problem P, int nb_rows) {
-  if (P.state->done) return;
+  const int done = P.state->done;   // checked before the store: the row loads are issued beside this load, not behind it
   __shared__ float red[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void k_theta_stage1(pf_problem P, int nb_rows)
   }
   red[rl][cl] = a;
   __syncthreads();
+  if (done) return;
   if (rl == 0 && col < P.pad_total) {
     const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
     P.partials[PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total + (size_t)blockIdx.y * P.pad_total + col] = t;
@@ -199,7 +200,9 @@ __global__ __launch_bounds__(256) void k_theta_stage1(pf_problem P, int nb_rows)
 
 // stage 2 (device function, one block): PF_RG partial rows -> grad_theta[q] (+ Adam, refreshed padded
 // image).  new_theta (LDS, n_theta_active floats) receives the updated parameters when non-null.
-__device__ __forceinline__ void theta_stage2(const pf_problem& P, int fuse_adam, float* new_theta) {
+// skip_stores: the (block-uniform) stop flag as loaded by the caller — the loads below are then issued WITH that load
+// instead of behind a branch on it (one global round trip less in a kernel that is nothing but round trips).
+__device__ __forceinline__ void theta_stage2(const pf_problem& P, int fuse_adam, float* new_theta, int skip_stores = 0) {
   PF_NO_CONTRACT
   const float* __restrict__ p2 = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total;
   const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
@@ -207,22 +210,27 @@ __device__ __forceinline__ void theta_stage2(const pf_problem& P, int fuse_adam,
   const float eps = (float)P.eps;
   for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
     const int pi = P.pad_index[q];
+    float th = P.theta[q];
+    float m = 0.f, v = 0.f;
+    if (fuse_adam) { m = P.m_t[q]; v = P.v_t[q]; }
     float g = 0.f;
 #pragma unroll
     for (int r = 0; r < PF_RG; ++r) g += p2[(size_t)r * P.pad_total + pi];
-    P.grad_theta[q] = g;
-    float th = P.theta[q];
     if (fuse_adam) {
-      float m = P.m_t[q], v = P.v_t[q];
       m = m + b1w * (g - m);
       v = v * b2;
       v = v + (b2w * g) * g;
       const float denom = sqrtf(v) / bc2s + eps;
       th = th + (-step_size) * (m / denom);
-      P.m_t[q] = m;
-      P.v_t[q] = v;
-      P.theta[q] = th;
-      P.theta_pad[pi] = th;
+    }
+    if (!skip_stores) {
+      P.grad_theta[q] = g;
+      if (fuse_adam) {
+        P.m_t[q] = m;
+        P.v_t[q] = v;
+        P.theta[q] = th;
+        P.theta_pad[pi] = th;
+      }
     }
     if (new_theta) new_theta[q] = th;
   }
@@ -267,11 +275,12 @@ __device__ __forceinline__ double tensor_norm_total(const pf_problem& P, const f
 // the iteration's theta-norm monitor from the LDS copy of the new parameters (state->theta_norm), so that the
 // bookkeeping (finalize_body with tn_ready) has no dependent chain of global loads left.
 __global__ __launch_bounds__(1024) void k_theta_stage2(pf_problem P, int fuse_adam) {
-  if (P.state->done) return;
+  const int done = P.state->done;        // acted on after the loads of the update have been issued
   extern __shared__ float new_theta[];   // n_theta_active floats (MFMA32 engine only)
   __shared__ float tnorm[PF_MAX_TENSORS];
   const bool ops = P.wg_mode == PF_WG_MFMA32 && fuse_adam;
-  theta_stage2(P, fuse_adam, ops ? new_theta : nullptr);
+  theta_stage2(P, fuse_adam, ops ? new_theta : nullptr, done);
+  if (done) return;
   if (ops) {
     __syncthreads();
     pack_net_ops(P, new_theta);           // operand entries: waves 0..3, scaling bound: the last wave
