@@ -2,9 +2,9 @@
 //
 // No reference analogue (the reference is single-process).  pinn_fem_amd/dist.py holds the
 // same schedule in Python over torch.distributed (used with gloo on CPU and for several ranks sharing one
-// GPU in tests); on real multi-GPU runs that loop is HOST-bound (5 graph replays + 2 torch collectives
-// per iteration ~ 280 us of host time against ~220 us of GPU time, measured on MI355X), so the product
-// path issues the kernels and the two ncclAllReduce per iteration from here: a handful of launches, no Python.
+// GPU in tests, 44-46 us of host time per iteration); the product path issues the ~11 kernels and the ONE
+// ncclAllReduce of an iteration from here (27-29 us of host time per iteration, measured on MI355X): no Python
+// in the loop.
 //
 // librccl is dlopen'ed from the path the host passes (the one PyTorch already loaded: same library
 // instance, second communicator); there is no link-time dependency on it.
