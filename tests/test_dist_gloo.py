@@ -25,7 +25,10 @@ def _run(kind, world, n_iter, tmp_path, port):
         return {k: z[k] for k in z.files}
 
 
-@pytest.mark.parametrize("kind,world,port", [("chain", 2, 29611), ("chain", 3, 29612), ("warren", 2, 29613)])
+# world 8 on the 37-element chain: 4-5 own elements per rank, interface rings of neighbouring cuts two elements apart
+# (the rank count of the driver's full-node run); world 4 on the Warren girder: shared nodes of degree 4
+@pytest.mark.parametrize("kind,world,port", [("chain", 2, 29611), ("chain", 3, 29612), ("warren", 2, 29613),
+                                             ("warren", 4, 29615), ("chain", 8, 29616)])
 def test_sharded_matches_single_process(kind, world, port, tmp_path):
     from dist_oracle_worker import build_problem
     n_iter = 15

@@ -348,10 +348,12 @@ def test_sharded_hip_example_run_two_ranks_one_gpu(tmp_path):
     assert abs(got["n_history"] - run["result"]["iterations"]) <= 3
 
 
-def test_sharded_hip_chain_matches_single_engine(tmp_path):
-    """300-element chain, 25 iterations: 3 ranks on one GPU == one engine (sum of shards == whole)."""
+@pytest.mark.parametrize("world,port", [(3, 29632), (4, 29636)])
+def test_sharded_hip_chain_matches_single_engine(tmp_path, world, port):
+    """300-element chain, 25 iterations: 3 and 4 ranks on one GPU == one engine (sum of shards == whole); with the test
+    process itself that is at most five processes on the card."""
     from pinn_fem_amd.fem.solver import SolverConfig, solve_gd
-    got = _run_hip_ranks("chain300", 3, tmp_path, 29632)
+    got = _run_hip_ranks("chain300", world, tmp_path, port)
     rec = load_npz("step_chain300_ex4shape.npz")
     model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, 10),
                           (1.0, 1.0, 1.0), theta_from(rec))
