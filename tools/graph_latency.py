@@ -10,7 +10,7 @@ from pinn_fem_amd.fem.solver import SolverConfig
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 model, mv, md, widths = build_model(n, "ex4")
-for gk in (10, 20, 5):
+for gk in (10, 2, 1):
     eng = HipEngine(model, mv, md)
     eng.GRAPH_ITERS = gk
     cfg = SolverConfig(max_iterations=100000, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
