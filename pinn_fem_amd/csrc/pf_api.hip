@@ -23,7 +23,6 @@ int pf_launch_adam(float* param, const float* grad, float* m, float* v, int n, i
                    double beta1, double beta2, double eps, hipStream_t s);
 int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s);
 int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s);
-int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, int u2_lag, hipStream_t s);
 
 static thread_local char g_err[512] = "";
 
@@ -640,9 +639,7 @@ int pf_shard_update_shared(const pf_problem* p, const float* buf, float* u2_loca
   if (!buf || !u2_local || !p->m_u || !p->v_u) return fail(PF_ERR_ARG, "null buffer");
   if (p->n_theta_active > 0 && (!p->m_t || !p->v_t)) return fail(PF_ERR_ARG, "null Adam moments for theta");
   hipStream_t s = (hipStream_t)stream;
-  PF_TRY(pf_launch_shard_update(p, buf, u2_local, s), "shard_update");
-  const float* tail = buf + p->n_iface + p->n_theta_active;
-  PF_TRY(pf_launch_finalize_from(p, tail, tail + 2, 1, s), "finalize_from");
+  PF_TRY(pf_launch_shard_update(p, buf, u2_local, s), "shard_update");   // (includes the iteration's bookkeeping)
   return PF_OK;
 }
 

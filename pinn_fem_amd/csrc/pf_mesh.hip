@@ -369,7 +369,7 @@ __device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int wi
     if (tn_ready) {
       tn = (double)tn_state;
     } else {
-      tensor_norms(P, with_theta ? new_theta : nullptr, threadIdx.x >> 6, blockDim.x >> 6, tnorm);
+      tensor_norms(P, new_theta, threadIdx.x >> 6, blockDim.x >> 6, tnorm);   // new_theta: LDS copy of the active parameters, or null
       __syncthreads();
       if (threadIdx.x == 0) tn = tensor_norm_total(P, tnorm);
     }
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
                                                              const float* __restrict__ ext_rd,
                                                              const float* __restrict__ ext_u2, int u2_lag, int tn_ready) {
   extern __shared__ float new_theta[];  // n_theta_active floats
-  finalize_body(P, nb_node, mode, with_theta, ext_rd, ext_u2, u2_lag, P.part_half, new_theta, tn_ready);
+  finalize_body(P, nb_node, mode, with_theta, ext_rd, ext_u2, u2_lag, P.part_half, with_theta ? new_theta : nullptr, tn_ready);
 }
 
 // ---- multi-GPU shard interface -------------------------------------------------------------------
@@ -509,6 +509,12 @@ __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node
   for (int i = threadIdx.x; i < nb_node; i += blockDim.x) c += (double)P.partials[PF_PART_U2 + i];
   const double tc = pf_block_sum_d(c, dred);
   if (threadIdx.x == 0) sums3[0] = (float)tc;
+  // the iteration's bookkeeping from the reduced sums, in the same block (one launch less per sharded iteration):
+  // [sum r^2, sum d^2] of this iteration and sum u_free^2 of the previous one (u2_lag) sit behind grad_theta in buf2
+  if (!new_theta) __threadfence_block();       // theta written above is read back from global memory
+  __syncthreads();
+  const float* tail = buf2 + P.n_iface + P.n_theta_active;
+  finalize_body(P, 0, 0, 0, tail, tail + 2, 1, 0, new_theta, 0);
 }
 
 // end of a chunk of sharded iterations: the last iteration's reduced sum u_free^2 completes the last history row
@@ -733,10 +739,6 @@ int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* u2_loc
   const int nb = pf_node_blocks(p->mesh.n_nodes);
   const size_t lds = p->wg_mode == PF_WG_MFMA32 ? (size_t)p->n_theta_active * sizeof(float) : 0;
   hipLaunchKernelGGL(k_shard_update, dim3(1), dim3(1024), lds, s, *p, nb, buf2, u2_local);
-  return PF_CHECK_LAUNCH();
-}
-int pf_launch_finalize_from(const pf_problem* p, const float* rd, const float* u2, int u2_lag, hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(PF_FIN_THREADS), 0, s, *p, 0, 0, 0, rd, u2, u2_lag, 0);
   return PF_CHECK_LAUNCH();
 }
 int pf_launch_shard_flush(const pf_problem* p, const float* u2, hipStream_t s) {
