@@ -465,15 +465,25 @@ constexpr int WAVE_SCRATCH = 2 * REGION;
 // complete: zero block Z at +192 (A hi), Z + SP_STRIDE (A lo), Z + REGION = bias block (B hi), Z + REGION + SP_STRIDE
 // (B lo).  Every lane therefore reads all four operands at ONE per-lane base plus compile-time offsets.
 constexpr int CONST_BYTES = COMPACT ? 6144 : 256;
-// waves per block (one block per CU): as many as the kernel's registers allow without spilling (checked in the
-// compiler's asm: ScratchSize 0 for every bucket) — 16 (four per SIMD, 128 registers) with one hidden layer, 12 (three
-// per SIMD, 168 registers) with two, else 8.  The MLP kernels are bound by the per-wave issue rate (one vector
-// instruction per ~4 cycles and wave), so waves per SIMD is what buys throughput.  A spill reload inside
-// the task loop is followed by s_waitcnt vmcnt(0), which also waits for the NEXT task's prefetched gathers: a spilling
-// 12-wave variant ran slower than the 8-wave one — hence the single per-lane LDS base (operand_base / write_base)
-// and the SGPR-held block-uniform scalars.
+// Waves per block (one block per CU) and the shape of the recompute.  Without pairing: as many waves as the kernel's
+// registers allow without spilling (ScratchSize 0 in the compiler's asm for every bucket) — 16 (four per SIMD, 128
+// registers) with one hidden layer, 12 with two, else 8.  A spill reload inside the task loop is followed by
+// s_waitcnt vmcnt(0), which also waits for the NEXT task's prefetched gathers: a spilling 12-wave variant ran slower
+// than the 8-wave one — hence the single per-lane LDS base (operand_base / write_base) and the SGPR-held block-uniform
+// scalars.  Going from 8 to 12 waves did NOT change the kernel time, though: the kernel is not short of waves.
+// PAIRED recompute: both tiles of a task go through the hidden layers together (forward_tiles, the forward kernel's
+// routine: twice the independent work in every MFMA / tanh / split phase) and only the back-propagation runs tile by
+// tile.  That needs ~200 registers, i.e. 8 waves per CU instead of 12 — and is FASTER (same box, 10^6 elements: E net
+// 51.6 -> 50.0 us, A net 40.0 -> 38.4 us): instruction-level parallelism inside a wave hides the MFMA -> tanh -> split
+// -> MFMA dependency chain better than a third wave does.  Used where it compiles without spills (ScratchSize 0 in
+// every bucket): two hidden layers, or three with PF_NR <= 8; one hidden layer keeps the per-tile form at 16 waves.
+template <int L>
+constexpr bool bw_pair() { return L == 2 || (L == 3 && NR <= 8); }
 template <int L, bool GEA>
-constexpr int bw_threads() { return !COMPACT ? 512 : (L == 1 ? 1024 : (L == 2 && !(GEA && NR > 10) ? 768 : 512)); }
+constexpr int bw_threads() {
+  if (bw_pair<L>()) return 512;
+  return !COMPACT ? 512 : (L == 1 ? 1024 : (L == 2 && !(GEA && NR > 10) ? 768 : 512));
+}
 
 // lane's pairs (hi or lo) of registers 0..15 -> split `sp` of the region at byte offset `reg` of the wave scratch.
 // wr0 / wr1: the lane's write positions of chunk 0 / chunk 1 in the A region's hi image (write_base).  bias_col: wide
@@ -747,13 +757,8 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
     float xa0, xa1, xb0, xb1;
     both_tiles(cur.x[1], xa0, xa1);
     both_tiles(cur.x[2], xb0, xb1);
-    // ---- the two tiles, one after the other ------------------------------------------------------------------
-    sfor<0, 2>([&](auto tt) {
-      constexpr int TT = tt;
-      const float xt[3] = {cur.x[0], TT ? xa1 : xa0, TT ? xb1 : xb0};
-      const float gt = TT ? g1 : g0;
-      TileAct<L, true> A;
-      recompute_tile<L, IN>(smem, lane, xt, A);
+    // ---- the two tiles ------------------------------------------------------------------------------------------
+    auto tile_backward = [&](const TileAct<L, true>& A, const float (&xt)[3], float gt) {
       // inputs of the combined tile: (KL lam, kx x, kx y, 1) resp. (KL lam, kx x, 1, 0)
       unsigned xhi[NPK], xlo[NPK];
       sfor<2, NPK>([&](auto q) { constexpr int Q = q; xhi[Q] = 0u; xlo[Q] = 0u; });
@@ -762,7 +767,23 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
       // (before backward_tile: a'_L is dead there, ten registers less at the kernel's pressure peak)
       sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = fmaf(gt, A.aL[R], go[R]); });
       if (!(dbg & 2)) backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, wb, rd, dbg);
-    });
+    };
+    if constexpr (bw_pair<L>()) {   // recompute both tiles together, then the two back-propagations (see bw_pair)
+      const float x0[3] = {cur.x[0], xa0, xb0}, x1[3] = {cur.x[0], xa1, xb1};
+      TileAct<L, true> A0, A1;
+      float p0, p1;
+      forward_tiles<L, IN, true>(smem, lane, x0, x1, A0, A1, p0, p1);
+      tile_backward(A0, x0, g0);
+      tile_backward(A1, x1, g1);
+    } else {
+      sfor<0, 2>([&](auto tt) {
+        constexpr int TT = tt;
+        const float xt[3] = {cur.x[0], TT ? xa1 : xa0, TT ? xb1 : xb0};
+        TileAct<L, true> A;
+        recompute_tile<L, IN>(smem, lane, xt, A);
+        tile_backward(A, xt, TT ? g1 : g0);
+      });
+    }
     gbo += gz;
   }
   const float invS = Srun == 0.f ? 1.0f : 1.0f / Srun;
