@@ -236,7 +236,11 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream);
 /* hipGraph form of pf_gd_iterations: capture `iters_per_graph` iterations once, replay many times
  * (removes the per-launch host cost and most of the inter-kernel gaps).  The graph bakes in the
  * pf_problem record by value: create it after the record is final (one per solve_gd call) and destroy
- * it before changing any field.  *graph_out is an opaque handle owned by the caller. */
+ * it before changing any field.  *graph_out is an opaque handle owned by the caller.  For >= 2e5 elements the
+ * captured iterations are a dependency DAG, not a chain: grad_u + Adam(u) runs beside the second net's backward, and
+ * the bookkeeping of iteration t (pf_finalize's work) runs as one extra block of the residual launch of t+1, reading
+ * the other half of the residual's partial sums (part_half); the last iteration of a replay gets a stand-alone
+ * pf_finalize.  Results are bit-identical to pf_gd_iterations. */
 int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void** graph_out);
 int pf_graph_launch(void* graph, void* stream);
 int pf_graph_destroy(void* graph);
