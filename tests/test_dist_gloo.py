@@ -105,3 +105,61 @@ def test_broadcast_theta_makes_replicas_identical(tmp_path):
     assert not np.array_equal(before[0], before[1]) and not np.array_equal(before[0], before[2])
     for k in range(3):
         assert np.array_equal(after[k], before[0])     # bit for bit rank 0's vector
+
+
+def test_partition_invariants_on_random_meshes():
+    """Structural invariants of the ghost-element partition on random connected meshes and rank counts up to 8: what
+    the one-collective schedule relies on (every element owned once, ghost ring complete, one global slot per
+    interface dof shared by all ranks that hold it, exactly one owner per node, interface closed under 'other node of
+    an element around a shared node')."""
+    from pinn_fem_amd.dist import partition_mesh
+    rng = np.random.default_rng(7)
+    for trial in range(12):
+        n_nodes = int(rng.integers(12, 90))
+        el = [(int(rng.integers(0, i)), i) for i in range(1, n_nodes)]            # a random tree: connected
+        for _ in range(int(rng.integers(0, n_nodes))):                           # + random chords
+            a, b = rng.choice(n_nodes, size=2, replace=False)
+            el.append((int(min(a, b)), int(max(a, b))))
+        el = np.array(el)
+        el = el[rng.permutation(len(el))]                                        # element order = ownership order
+        dim = int(rng.integers(1, 3))
+        world = int(rng.integers(2, 9))
+        if len(el) < world:
+            continue
+        shards = [partition_mesh(el, n_nodes, dim, r, world) for r in range(world)]
+        # every element owned exactly once, own range = contiguous slice of the local list
+        owned = np.concatenate([s.elems_global[s.own_lo:s.own_hi] for s in shards])
+        assert sorted(owned) == list(range(len(el)))
+        for s in shards:
+            assert list(s.elems_global[s.own_lo:s.own_hi]) == list(range(s.elem_lo, s.elem_hi))
+            assert np.all(np.diff(s.elems_global) > 0)
+        # shared nodes: touched by own elements of more than one rank
+        touch = [set(np.unique(el[s.elem_lo:s.elem_hi])) for s in shards]
+        count = np.zeros(n_nodes, dtype=int)
+        for t in touch:
+            count[list(t)] += 1
+        shared = set(np.flatnonzero(count > 1))
+        for r, s in enumerate(shards):
+            my_shared = touch[r] & shared
+            ring = set(np.flatnonzero(np.isin(el, list(my_shared)).any(axis=1))) if my_shared else set()
+            assert set(s.elems_global) == set(range(s.elem_lo, s.elem_hi)) | ring          # own + complete ghost ring
+        # the global interface: shared nodes and the other nodes of the elements around them
+        iface_nodes = set(shared)
+        for e in np.flatnonzero(np.isin(el, list(shared)).any(axis=1)) if shared else []:
+            iface_nodes |= set(el[e])
+        n_iface = dim * len(iface_nodes)
+        slot_of = {}
+        for s in shards:
+            assert s.n_iface == n_iface
+            gdofs = (np.asarray(s.nodes_global)[s.shared_dofs // dim] * dim + s.shared_dofs % dim)
+            assert set(gdofs // dim) == iface_nodes & set(s.nodes_global)               # every local copy takes part
+            for g, k in zip(gdofs, s.shared_slot):
+                assert slot_of.setdefault(int(g), int(k)) == int(k)                       # same slot on every rank
+        assert sorted(slot_of.values()) == list(range(n_iface))
+        # exactly one owner per node among the ranks whose own elements touch it (isolated nodes do not occur)
+        owners = np.zeros(n_nodes, dtype=int)
+        for r, s in enumerate(shards):
+            mine = np.asarray(s.nodes_global)[~s.ghost_mask[0::dim]]
+            assert set(mine) <= touch[r]
+            owners[mine] += 1
+        assert np.all(owners[sorted(set().union(*touch))] == 1)
