@@ -14,6 +14,18 @@ sys.path.insert(0, HERE)
 os.environ.setdefault("PINNFEM_QUIET", "1")
 
 
+def random_case(seed):
+    """(model, config, measured values, measured dofs) of the random-truss case; solve_gd(*random_case(seed))."""
+    from dist_oracle_worker import random_truss
+    from helpers import load_npz, product_model, theta_from
+    from pinn_fem_amd.fem.solver import SolverConfig
+    rec = load_npz("step_warren_EA.npz")
+    nodes, el, loads, fixed, md, mv = random_truss(seed)
+    model = product_model(nodes, el, loads, fixed, 2, (20, 15, None), (2.0, 0.5, 1.0), theta_from(rec))
+    cfg = SolverConfig(max_iterations=20, learning_rate_u=1e-3, learning_rate_theta=5e-4, tolerance=1e-12)
+    return model, cfg, mv, md, 0.7
+
+
 def main():
     kind, out = sys.argv[1], sys.argv[2]
     dist.init_process_group("gloo")
@@ -35,6 +47,8 @@ def main():
         cfg = SolverConfig(max_iterations=20, learning_rate_u=1e-3, learning_rate_theta=5e-4, tolerance=1e-12)
         res = solve_gd(model, cfg, rec["meas_vals"], rec["meas_dofs"], target_load_factor=0.7,
                        u_initial=torch.from_numpy(rec["u"]))
+    elif kind.startswith("rand"):  # the Warren fixture's nets on a random truss with shuffled element order
+        res = solve_gd(*random_case(int(kind[4:] or 0)))
     else:  # a 300-element chain, 25 iterations from the fixture state
         rec = load_npz("step_chain300_ex4shape.npz")
         model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, 10),

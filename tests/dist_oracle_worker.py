@@ -132,8 +132,32 @@ class OracleShardBackend(ShardBackend):
             self.history[-1]["u_norm"] = float(np.sqrt(f32(float(u2_reduced[0]))))
 
 
+def random_truss(seed, n_nodes=40):
+    """A random connected planar truss (spanning tree + chords, element order shuffled, so rank boundaries cut through
+    nodes of any degree): nodes, elements, loads, fixed dofs, measured dofs/values."""
+    rng = np.random.default_rng(seed)
+    nodes = np.stack([rng.uniform(0.0, 8.0, n_nodes), rng.uniform(0.0, 3.0, n_nodes)], axis=1)
+    el = {(int(rng.integers(0, i)), i) for i in range(1, n_nodes)}
+    while len(el) < 2 * n_nodes:
+        a, b = rng.choice(n_nodes, size=2, replace=False)
+        el.add((int(min(a, b)), int(max(a, b))))
+    el = np.array(sorted(el))[rng.permutation(len(el))]
+    fixed = np.unique(np.concatenate([[0, 1, 2, 3], rng.choice(np.arange(4, 2 * n_nodes), size=5, replace=False)]))
+    loads = np.zeros(2 * n_nodes)
+    loads[rng.choice(2 * n_nodes, size=6, replace=False)] = rng.uniform(-0.5, 0.5, 6)
+    meas_dofs = np.setdiff1d(np.arange(2 * n_nodes), fixed)
+    meas_vals = rng.normal(size=meas_dofs.size) * 0.05
+    return nodes, el, loads, fixed, meas_dofs, meas_vals
+
+
 def build_problem(kind):
     from helpers import load_npz, mesh_problem
+    if kind.startswith("rand"):
+        # the Warren fixture's networks (E net 20 wide, A net 15 wide) on a random truss
+        base = mesh_problem(load_npz("step_warren_EA.npz"), (20, 15, None), (2.0, 0.5, 1.0))
+        nodes, el, loads, fixed, md, mv = random_truss(int(kind[4:] or 0))
+        return orc.Problem(nodes=nodes, elements=el, loads=loads, fixed_dofs=fixed, dimension=2, young=base.young,
+                           area=base.area, density=base.density, measured_vals=mv, measured_dofs=md)
     if kind == "warren":
         return mesh_problem(load_npz("step_warren_EA.npz"), (20, 15, None), (2.0, 0.5, 1.0))
     rec = load_npz("step_chain300_ex4shape.npz")

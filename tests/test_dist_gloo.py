@@ -26,9 +26,11 @@ def _run(kind, world, n_iter, tmp_path, port):
 
 
 # world 8 on the 37-element chain: 4-5 own elements per rank, interface rings of neighbouring cuts two elements apart
-# (the rank count of the driver's full-node run); world 4 on the Warren girder: shared nodes of degree 4
+# (the rank count of the driver's full-node run); world 4 on the Warren girder: shared nodes of degree 4; random
+# trusses with shuffled element order (dist_oracle_worker.random_truss): cuts through nodes of any degree
 @pytest.mark.parametrize("kind,world,port", [("chain", 2, 29611), ("chain", 3, 29612), ("warren", 2, 29613),
-                                             ("warren", 4, 29615), ("chain", 8, 29616)])
+                                             ("warren", 4, 29615), ("chain", 8, 29616),
+                                             ("rand1", 3, 29617), ("rand2", 5, 29618)])
 def test_sharded_matches_single_process(kind, world, port, tmp_path):
     from dist_oracle_worker import build_problem
     n_iter = 15

@@ -385,6 +385,21 @@ def test_sharded_hip_warren_truss_matches_single_engine(tmp_path):
         assert rel_err(got["theta"][k], v.reshape(-1)) < 2e-5, k
 
 
+def test_sharded_hip_random_truss_matches_single_engine(tmp_path):
+    """A random connected truss with shuffled element order (40 nodes, 80 elements; rank boundaries cut through nodes of
+    any degree, ghost rings several elements wide) on 3 ranks sharing this GPU == one engine, 20 iterations."""
+    from dist_hip_worker import random_case
+    from pinn_fem_amd.fem.solver import solve_gd
+    got = _run_hip_ranks("rand3", 3, tmp_path, 29637)
+    model, cfg, mv, md, lam = random_case(3)
+    ref = solve_gd(model, cfg, mv, md, lam)
+    assert got["n_history"] == 20
+    assert rel_err(got["u"], ref.displacements.flatten()) < 2e-5
+    assert rel_err(got["loss"], [h["loss_total"] for h in ref.history]) < 1e-4
+    for k, v in ref.nn_parameters.items():
+        assert rel_err(got["theta"][k], v.reshape(-1)) < 2e-5, k
+
+
 def test_api_pinn_gd_identifies_stiffness(tmp_path):
     """api_pinn_gradient_descent.py end to end on the GPU: a 3-bar chain whose measured displacements
     correspond to E*A = 2; the identified product must move from the initial guess (1) towards 2 and
