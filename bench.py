@@ -283,6 +283,7 @@ def main():
     assert st.iter == iters_before + n_warm + args.steps, (st.iter, iters_before + n_warm + args.steps)
     assert graph_count() == graphs_before, "a hipGraph was captured inside the timed region"
 
+    mlp_dtype = (eng if world == 1 else eng.backend.eng).mlp_dtype
     if rank == 0:
         total_elems = n_local * world
         value = total_elems * args.steps / dt
@@ -327,7 +328,10 @@ def main():
             "value": value, "unit": "element-evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "warmup_iterations_run": n_warm, "graph_captured_before_timing": world == 1,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "scaling": "weak", "vs_baseline": None,
+            # arithmetic type of the path: f32 throughout, unless the optional bf16-operand MLP was switched on
+            # (PINNFEM_MLP_DTYPE=bf16: hidden-layer products on bf16 operands, everything else f32)
+            "dtype": "f32" if mlp_dtype == "f32" else "bf16 (hidden-layer products; f32 elsewhere)",
             "data": "synthetic" + (" (ONE-GPU REHEARSAL: not a valid multi-GPU number)" if rehearsal else ""),
             "config": {"workload": f"{args.workload} shape (nets {widths}, E and A evaluated), "
                                    f"{n_local} elements per GPU, collinear 2-D truss h=1, "
