@@ -361,11 +361,11 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
 //   backward #1 (+gea)  g_f; it is the last reader of u(t)
 //   gradu + Adam(u)     g_f, the properties, backward #1 done; the Adam scalars                [finalize of t-1]
 //   backward #2, theta stage 1, stage 2 + Adam(theta)   in this order after backward #1
-//   finalize            stage 2 and gradu of t
-// so gradu (HBM bound) runs on branch A beside backward #2 and the theta reduction (compute bound), and
-// finalize runs on branch B beside the next iteration's forward kernels.  The stop flag is read by every
-// kernel at its start; a kernel of t+1 that misses a stop raised by finalize(t) only rewrites scratch
-// (properties, g_f, partial sums): everything that changes solver state (both Adam kernels, finalize)
+//   finalize(t)         stage 2 and gradu of t: it runs inside node_residual(t+1) (PF_GRAPH_FIN=branch: as a node of its
+//                       own on a second side branch, the round-1 form)
+// so gradu (HBM bound) runs on branch A beside backward #2 and the theta reduction (compute bound).  The stop flag
+// is read by every kernel at its start; a kernel of t+1 that misses a stop raised by finalize(t) only rewrites scratch
+// (properties, g_f, partial sums): everything that changes solver state (both Adam kernels, the next finalize)
 // is ordered behind finalize(t) and returns at once, so the final state is the reference's `break`.
 #define PF_CAP_EV 6
 // below this many elements the kernels are too short to hide anything behind: the branches' fork/join cost

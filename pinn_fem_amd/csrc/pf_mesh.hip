@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_pack_theta(pf_problem P) {
 
 // ---- parameter update + monitors / history / stop test / next Adam scalars ------------------------
 // mode 0: full iteration bookkeeping incl. theta stage 2 + Adam (solver.py:293-294, 304-355);
-// mode 1: losses + gradient reduction only (autograd binding).  One block of 1024 threads.
+// mode 1: losses + gradient reduction only (autograd binding).
 // ext_rd / ext_u2 (multi-GPU): globally reduced [sum r^2, sum d^2] and [sum u_free^2] to use instead of
 // this rank's block partials (which already belong to the next iteration when this runs).
 // u2_lag (multi-GPU): ext_u2 is the sum of the PREVIOUS iteration (it travelled on this iteration's all-reduce):
