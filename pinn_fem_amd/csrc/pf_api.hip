@@ -388,13 +388,19 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   // PF_GRAPH_SERIAL=1: experiment knob, the plain chain of launches inside the graph (no branches)
   static const int serial_knob = getenv("PF_GRAPH_SERIAL") ? atoi(getenv("PF_GRAPH_SERIAL")) : -1;
   const bool serial = serial_knob >= 0 ? serial_knob != 0 : p->mesh.n_elems < PF_GRAPH_DAG_MIN_ELEMS;
-  if (!any_net || serial) {
+  if (!any_net) {
     for (int i = 0; i < iters; ++i) {
       int rc = enqueue_iteration(p, 1, 0, s, nullptr);
       if (rc != PF_OK) return rc;
     }
     return PF_OK;
   }
+  // serial: the same kernels as ONE chain on `s` (no side branch, no events): forwards, residual [+ finalize of the
+  // previous iteration in its block 0], backwards, theta stage 1 + 2, gradu — the bookkeeping costs no launch of its
+  // own there either (the eager sequence ends with a single-block kernel that does theta stage 2 AND the bookkeeping).
+  hipStream_t sa = serial ? s : c.a;
+  auto ev_wait = [&](hipStream_t st, hipEvent_t e) { return serial || hipStreamWaitEvent(st, e, 0) == hipSuccess; };
+  auto ev_rec = [&](hipEvent_t e, hipStream_t st) { return serial || hipEventRecord(e, st) == hipSuccess; };
   const bool fuse_gea = fuse_gea_for(p);
   const int first = p->net[0].enabled ? 0 : 1;
   // The runtime keeps the FIRST-created child of a node on its parent's hardware queue and moves later
@@ -422,14 +428,14 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
       if (q.elem_s) q.elem_s += q.mesh.n_elems;
     }
     q.part_half = i & 1;
-    if (i > 0 && !pingpong && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    if (i > 0 && !pingpong && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
     // (the two forwards run one after the other: side by side on two branches they measured slower, 0.195 vs
     // 0.190 ms per iteration with the f32 engine — the same issue pipe — and the second one writes elem_s from both)
     for (int k = 0; k < 2; ++k)
       if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
     // residual(i) reads u(i) [gradu(i-1)]; its block 0 is finalize(i-1): behind stage 2 (this chain) and gradu(i-1)
-    if (i > 0 && hipStreamWaitEvent(s, ep[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    if (fin_branch && i > 0) {
+    if (i > 0 && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
+    if (fin_branch && !serial && i > 0) {
       // the older form (PF_GRAPH_FIN=branch): finalize(i-1) as a node of its own on a second side branch, beside the forwards
       if (hipStreamWaitEvent(c.b, ep[2], 0) != hipSuccess || hipStreamWaitEvent(c.b, ep[1], 0) != hipSuccess)
         return fail(PF_ERR_HIP, "graph edge failed");
@@ -439,26 +445,26 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
       if (hipEventRecord(ep[3], c.b) != hipSuccess || hipStreamWaitEvent(s, ep[3], 0) != hipSuccess)
         return fail(PF_ERR_HIP, "graph edge failed");
     }
-    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, i > 0 && !fin_branch ? (tn_ready ? 2 : 1) : 0), "node_residual");
+    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, i > 0 && !(fin_branch && !serial) ? (tn_ready ? 2 : 1) : 0), "node_residual");
     if (!fuse_gea) {
       PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
-      if (hipEventRecord(e[0], s) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+      if (!ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
     }
     for (int k = 0; k < 2; ++k) {
       if (!p->net[k].enabled) continue;
       PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
-      if (fuse_gea && k == first && hipEventRecord(e[0], s) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+      if (fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
     }
     PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
     PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
-    if (hipEventRecord(e[2], s) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    if (!ev_rec(e[2], s)) return fail(PF_ERR_HIP, "graph edge failed");
     // branch A (created after the main chain's nodes of this iteration): gradu behind the last reader of u
-    if (hipStreamWaitEvent(c.a, e[0], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
-    PF_TRY(pf_launch_node_gradu(p, 1, c.a), "node_gradu");
-    if (hipEventRecord(e[1], c.a) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+    if (!ev_wait(sa, e[0])) return fail(PF_ERR_HIP, "graph edge failed");
+    PF_TRY(pf_launch_node_gradu(p, 1, sa), "node_gradu");
+    if (!ev_rec(e[1], sa)) return fail(PF_ERR_HIP, "graph edge failed");
   }
   // finalize of the last iteration: behind stage 2 (this chain) and the last gradu
-  if (hipStreamWaitEvent(s, c.ev[PF_CAP_EV * (iters - 1) + 1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
+  if (!ev_wait(s, c.ev[PF_CAP_EV * (iters - 1) + 1])) return fail(PF_ERR_HIP, "graph join failed");
   {
     pf_problem q = *p;
     q.part_half = (iters - 1) & 1;
