@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 5
+#define PF_ABI_VERSION 6
 
 /* error codes */
 #define PF_OK 0
@@ -172,6 +172,10 @@ typedef struct pf_problem {
    * of the LAST evaluated net (same float operations as nn_assembly.py:74) and read by the node kernels instead of
    * E, A and l0; NULL: the node kernels compute it from prop_e / prop_a / the constant properties */
   float* elem_s;
+  /* per CSR entry of mesh.adj: the node at the OTHER end of that element ([adj_ptr[n_nodes]] int32).  With it the node
+   * kernels fetch a neighbour's values one dependent load earlier (adj -> value instead of adj -> conn -> value) and
+   * two incidences at a time; NULL: they go through mesh.conn. */
+  const int32_t* adj_other;
 } pf_problem;
 
 #define PF_MAX_BLOCKS 1024

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpinnfem_hip.so")
 
-PF_ABI_VERSION = 5
+PF_ABI_VERSION = 6
 PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_DOF_FIXED, PF_DOF_MEASURED, PF_DOF_SHARED, PF_DOF_GHOST = 1, 2, 4, 8
 PF_WG_SHUFFLE, PF_WG_MFMA, PF_WG_MFMA44, PF_WG_MFMA32 = 0, 1, 2, 3
@@ -83,7 +83,7 @@ class PfProblem(C.Structure):
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
         ("own_lo", C.c_int32), ("own_hi", C.c_int32), ("part_half", C.c_int32), ("prop_double", C.c_int32),
         ("net_op", C.c_void_p), ("op_off", C.c_int32 * 2), ("coord_exp", C.c_int32), ("mlp_dtype", C.c_int32),
-        ("elem_s", C.c_void_p),
+        ("elem_s", C.c_void_p), ("adj_other", C.c_void_p),
     ]
 
 

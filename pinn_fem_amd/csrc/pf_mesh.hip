@@ -36,6 +36,37 @@ __device__ __forceinline__ void gather_kv(const pf_problem& P, const float* __re
 #pragma unroll
   for (int c = 0; c < DIM; ++c) acc[c] = 0.f;
   const int b = M.adj_ptr[node], e_ = M.adj_ptr[node + 1];
+  if (P.adj_other) {
+    // Three dependent round trips per node whatever its degree (<= 2 per round): adj_ptr -> (adj, adj_other) of two
+    // incidences -> (geometry, stiffness, neighbour values) of both -> arithmetic in ascending element order (the
+    // reference's accumulation order, as below).  The node's own entries need no indirection at all.
+    float vs[2];
+    load_vec<DIM>(v, node, vs);
+    for (int idx = b; idx < e_; idx += 2) {
+      const bool two = idx + 1 < e_;
+      const int code0 = M.adj[idx], oth0 = P.adj_other[idx];
+      const int code1 = two ? M.adj[idx + 1] : code0, oth1 = two ? P.adj_other[idx + 1] : oth0;
+      const int e0 = code0 >> 1, e1 = code1 >> 1;
+      const ElemGeo g0 = load_geo(M.egeo, e0), g1 = load_geo(M.egeo, e1);
+      const float s0 = elem_stiffness(P, e0, g0.l0), s1 = elem_stiffness(P, e1, g1.l0);
+      float vo0[2], vo1[2], fe[2];
+      load_vec<DIM>(v, oth0, vo0);
+      load_vec<DIM>(v, oth1, vo1);
+      if (!(own_only && (e0 < P.own_lo || e0 >= P.own_hi))) {
+        const int end = code0 & 1;
+        ke_rows_times<DIM>(g0, s0, end, end ? vo0 : vs, end ? vs : vo0, fe, P.fe_mode);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) acc[c] += fe[c];
+      }
+      if (two && !(own_only && (e1 < P.own_lo || e1 >= P.own_hi))) {
+        const int end = code1 & 1;
+        ke_rows_times<DIM>(g1, s1, end, end ? vo1 : vs, end ? vs : vo1, fe, P.fe_mode);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) acc[c] += fe[c];
+      }
+    }
+    return;
+  }
   for (int idx = b; idx < e_; ++idx) {
     const int code = M.adj[idx];
     const int e = code >> 1, end = code & 1;
@@ -121,7 +152,7 @@ __global__ __launch_bounds__(256) void k_elem_adjoint(pf_problem P) {
 // skip_shared (multi-GPU): shared dofs are left alone; their gradient is completed by the second
 // all-reduce and pf_shard_update_shared steps them.
 template <int DIM, bool FUSE_ADAM>
-__global__ __launch_bounds__(PF_NODE_THREADS) void k_node_gradu(pf_problem P, int skip_shared) {
+__global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void k_node_gradu(pf_problem P, int skip_shared) {
   PF_NO_CONTRACT
   if (P.state->done) return;
   __shared__ float red[16];

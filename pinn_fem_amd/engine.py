@@ -56,7 +56,7 @@ class HipEngine:
         dev = self.device
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.conn, self.egeo, self.ecent = t(hp.conn), t(hp.egeo), t(hp.ecent)
-        self.adj_ptr, self.adj = t(hp.adj_ptr), t(hp.adj)
+        self.adj_ptr, self.adj, self.adj_other = t(hp.adj_ptr), t(hp.adj), t(hp.adj_other)
         self.f_ext, self.dof_flags, self.meas_val = t(hp.f_ext), t(hp.dof_flags), t(hp.meas_val)
         self.has_measurements = measured_disp is not None and measured_dofs is not None
         # multi-GPU shard interface: (interface dofs int32[], their slots int32[], n_iface, (own_lo, own_hi))
@@ -250,6 +250,7 @@ class HipEngine:
         P.coord_exp = self.coord_exp
         P.mlp_dtype = _capi.PF_MLP_BF16 if self.mlp_dtype == "bf16" else _capi.PF_MLP_F32
         P.elem_s = self.elem_s.data_ptr() if self.elem_s is not None else None
+        P.adj_other = self.adj_other.data_ptr()
         self._configured = True
 
     def _ref(self):

@@ -28,6 +28,7 @@ class HostPlan:
     ecent: np.ndarray      # float32 [n_elems,dim]
     adj_ptr: np.ndarray    # int32 [n_nodes+1]
     adj: np.ndarray        # int32 [2*n_elems]  (elem<<1)|end, ascending element id per node
+    adj_other: np.ndarray  # int32 [2*n_elems]  node at the other end of that element
     f_ext: np.ndarray      # float32 [n_dofs]
     dof_flags: np.ndarray  # uint8 [n_dofs]
     meas_val: np.ndarray   # float32 [n_dofs]
@@ -116,6 +117,7 @@ def build_host_plan(nodes, elements, loads, fixed_dofs, dimension: int,
         egeo=np.ascontiguousarray(egeo, dtype=np.float32),
         ecent=np.ascontiguousarray(ecent, dtype=np.float32),
         adj_ptr=adj_ptr.astype(np.int32), adj=order.astype(np.int32),
+        adj_other=np.ascontiguousarray(flat[order ^ 1], dtype=np.int32),     # position k^1 = the element's other end
         f_ext=loads.astype(np.float32), dof_flags=flags, meas_val=meas_val, n_meas=n_meas,
         free_dofs=free, fixed_dofs=fixed)
 
