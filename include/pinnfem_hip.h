@@ -297,6 +297,15 @@ int pf_comm_info(void* comm, int* rank_out, int* nranks_out);
 /* sum over ranks of buf[0..n), in place, on `stream` (the collective pf_shard_iterations issues, on its own) */
 int pf_comm_all_reduce(void* comm, float* buf, int n, void* stream);
 int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf, float* u2_local, void* stream);
+/* iters_per_graph sharded iterations as ONE hipGraph with the collective captured inside (handle for pf_graph_destroy):
+ * the single-engine iteration's dependency shape (grad_u + Adam(u) of the interior dofs beside the second backward and
+ * the collective) without a host launch per kernel.  It bakes in *p, buf, u2_local and the communicator; every rank
+ * must create and replay it alike.  pf_shard_iterations_graph = pf_shard_iterations replaying that graph for whole
+ * multiples of iters_per_graph and launching the remainder eagerly; results are bit-identical to pf_shard_iterations. */
+int pf_shard_graph_create(const pf_problem* p, void* comm, int iters_per_graph, float* buf, float* u2_local, void* stream,
+                          void** graph_out);
+int pf_shard_iterations_graph(const pf_problem* p, void* comm, void* graph, int iters_per_graph, int n_iter, float* buf,
+                              float* u2_local, void* stream);
 
 /* ---- classical Newton-Raphson support (pf_pcg.hip) ---------------------------
  * The reference's solve_nr (FEM/python/fem/solver.py:408-512) solves K_ff du_f = rhs_f with

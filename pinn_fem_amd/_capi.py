@@ -132,6 +132,10 @@ SYMBOLS = {
     "pf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pf_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pf_shard_iterations": (C.c_int, [_PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pf_shard_graph_create": (C.c_int, [_PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_void_p)]),
+    "pf_shard_iterations_graph": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p]),
     "pf_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pf_diag_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),

@@ -473,15 +473,13 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   return PF_OK;
 }
 
-int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void** graph_out) {
-  int rc = check_gd(p);
-  if (rc) return rc;
-  if (!graph_out || iters_per_graph < 1) return fail(PF_ERR_ARG, "pf_graph_create: bad argument");
-  hipStream_t s = (hipStream_t)stream;
+}  // extern "C"
+// capture fn(capture streams/events) on `s` (+ two side streams) and instantiate the graph
+template <class F>
+static int capture_graph(hipStream_t s, int nev, hipStreamCaptureMode mode, void** graph_out, F&& fn) {
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   hipStream_t side[2] = {nullptr, nullptr};
-  const int nev = PF_CAP_EV * iters_per_graph;
   hipEvent_t* ev = new hipEvent_t[nev];
   int made = 0;
   bool ok = hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking) == hipSuccess &&
@@ -490,35 +488,44 @@ int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void
     if (hipEventCreateWithFlags(&ev[made], hipEventDisableTiming) != hipSuccess) break;
   ok = ok && made == nev;
   auto cleanup = [&]() {
-    for (int i = 0; i < made; ++i) hipEventDestroy(ev[i]);
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
     delete[] ev;
     for (int k = 0; k < 2; ++k)
-      if (side[k]) hipStreamDestroy(side[k]);
+      if (side[k]) (void)hipStreamDestroy(side[k]);
   };
   if (!ok) {
     cleanup();
-    return fail(PF_ERR_HIP, "pf_graph_create: stream/event creation failed");
+    return fail(PF_ERR_HIP, "graph capture: stream/event creation failed");
   }
-  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+  if (hipStreamBeginCapture(s, mode) != hipSuccess) {
     cleanup();
     return fail(PF_ERR_HIP, "hipStreamBeginCapture failed");
   }
   pf_capture cap{s, side[0], side[1], ev};
-  rc = enqueue_graph_iterations(p, iters_per_graph, cap);
+  const int rc = fn(cap);
   const hipError_t e = hipStreamEndCapture(s, &graph);
   cleanup();
   if (rc != PF_OK) {
-    if (graph) hipGraphDestroy(graph);
+    if (graph) (void)hipGraphDestroy(graph);
     return rc;
   }
   if (e != hipSuccess || !graph) return fail(PF_ERR_HIP, "hipStreamEndCapture failed");
   if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     return fail(PF_ERR_HIP, "hipGraphInstantiate failed");
   }
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   *graph_out = (void*)exec;
   return PF_OK;
+}
+extern "C" {
+
+int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void** graph_out) {
+  int rc = check_gd(p);
+  if (rc) return rc;
+  if (!graph_out || iters_per_graph < 1) return fail(PF_ERR_ARG, "pf_graph_create: bad argument");
+  return capture_graph((hipStream_t)stream, PF_CAP_EV * iters_per_graph, hipStreamCaptureModeThreadLocal, graph_out,
+                       [&](pf_capture& cap) { return enqueue_graph_iterations(p, iters_per_graph, cap); });
 }
 
 int pf_graph_launch(void* graph, void* stream) {
@@ -638,6 +645,67 @@ int pf_shard_update_interior(const pf_problem* p, void* stream) {
   PF_TRY(pf_launch_node_gradu(p, 1, (hipStream_t)stream, 1), "node_gradu");
   return PF_OK;
 }
+
+}  // extern "C"
+// `iters` complete sharded iterations as ONE hipGraph, the collective included (all_reduce: the caller's, captured on
+// the main stream like a kernel).  Per iteration: forwards, residual, first backward -> [fork: gradu of the interior
+// dofs] -> second backward, theta stage 1, pack -> all-reduce(buf) -> [join] -> interface update + bookkeeping; i.e.
+// the single-engine iteration's shape with the collective on the chain and gradu hidden beside the second backward
+// and the collective.  Internal (pf_comm.hip: pf_shard_graph_create).
+int pf_shard_graph_capture(const pf_problem* p, int iters, float* buf, float* u2_local, hipStream_t stream,
+                           int (*all_reduce)(void* ctx, float* buf, size_t n, hipStream_t s), void* ctx, void** graph_out) {
+  int rc = check_shared(p);
+  if (rc) return rc;
+  if (!buf || !u2_local || !graph_out || !all_reduce || iters < 1 || !p->m_u || !p->v_u)
+    return fail(PF_ERR_ARG, "pf_shard_graph_capture: bad argument");
+  if (p->n_theta_active > 0 && (p->grad_theta != buf + p->n_iface || !p->m_t || !p->v_t))
+    return fail(PF_ERR_ARG, "p->grad_theta must point at buf + n_iface (and the theta moments must exist)");
+  const size_t n = (size_t)p->n_iface + (size_t)p->n_theta_active + 3;
+  // relaxed capture mode: the collective library may call into the runtime while it enqueues
+  return capture_graph(stream, 2 * iters, hipStreamCaptureModeRelaxed, graph_out, [&](pf_capture& c) -> int {
+    hipStream_t s = c.s;
+    const bool any_net = p->net[0].enabled || p->net[1].enabled;
+    for (int i = 0; i < iters; ++i) {
+      hipEvent_t* e = c.ev + 2 * i;
+      for (int k = 0; k < 2; ++k)
+        if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
+      PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
+      bool marked = false;                  // e[0]: the last reader of u (the element adjoint) is done
+      auto mark = [&]() {
+        marked = true;
+        return hipEventRecord(e[0], s) == hipSuccess;
+      };
+      if (any_net) {
+        const pf_problem q = own_view(p);
+        const bool fuse_gea = fuse_gea_for(&q);
+        const int first = q.net[0].enabled ? 0 : 1;
+        if (!fuse_gea) {
+          PF_TRY(pf_launch_elem_adjoint(&q, s), "elem_adjoint");
+          if (!mark()) return fail(PF_ERR_HIP, "graph edge failed");
+        }
+        for (int k = 0; k < 2; ++k) {
+          if (!q.net[k].enabled) continue;
+          PF_TRY(fuse_gea && k == first ? net_backward_gea(&q, k, s) : net_backward(&q, k, s), "net_backward");
+          if (fuse_gea && k == first && !mark()) return fail(PF_ERR_HIP, "graph edge failed");
+        }
+        PF_TRY(pf_launch_theta_stage1(&q, s), "theta_stage1");
+      }
+      if (!marked && !mark()) return fail(PF_ERR_HIP, "graph edge failed");
+      PF_TRY(pf_launch_shard_pack(p, buf, u2_local, s), "shard_pack");
+      // the side branch is created AFTER the chain's nodes of this iteration: the runtime keeps the first-created child of
+      // a node on its parent's hardware queue, and the chain must be the one that stays (pf_graph_create, same rule)
+      if (hipStreamWaitEvent(c.a, e[0], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+      PF_TRY(pf_launch_node_gradu(p, 1, c.a, 1), "node_gradu");
+      if (hipEventRecord(e[1], c.a) != hipSuccess) return fail(PF_ERR_HIP, "graph edge failed");
+      int r3 = all_reduce(ctx, buf, n, s);
+      if (r3 != PF_OK) return r3;
+      if (hipStreamWaitEvent(s, e[1], 0) != hipSuccess) return fail(PF_ERR_HIP, "graph join failed");
+      PF_TRY(pf_launch_shard_update(p, buf, u2_local, s), "shard_update");
+    }
+    return PF_OK;
+  });
+}
+extern "C" {
 
 int pf_shard_update_shared(const pf_problem* p, const float* buf, float* u2_local, void* stream) {
   int rc = check_shared(p);

@@ -133,6 +133,19 @@ extern "C" {
     if (rc__ != PF_OK) return rc__; \
   } while (0)
 
+}  // extern "C"
+// flush: the last iteration's sum u^2, reduced in the (free) last slot of buf — u2_local keeps the LOCAL sum, the next
+// chunk's first all-reduce carries it again
+static int shard_flush(const pf_problem* p, pf_comm* c, float* buf, size_t n, const float* u2_local, hipStream_t s) {
+  float* slot = buf + n - 1;
+  if (hipMemcpyAsync(slot, u2_local, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return comm_fail(PF_ERR_HIP, "pf_shard_iterations", "hipMemcpyAsync failed");
+  PF_RUN(all_reduce(c, slot, 1, s));
+  PF_RUN(pf_shard_flush(p, slot, (void*)s));
+  return PF_OK;
+}
+extern "C" {
+
 // n_iter sharded iterations and the closing flush, everything in stream order on `stream`:
 //   forward, backward (+ pack), interior update  ->  all-reduce(buf)  ->  interface update + bookkeeping
 // buf = [iface grad_u | grad_theta | r2, d2, u2 of the previous iteration], u2_local = this rank's last sum u_free^2.
@@ -149,16 +162,38 @@ int pf_shard_iterations(const pf_problem* p, void* comm, int n_iter, float* buf,
     PF_RUN(all_reduce(c, buf, n, s));
     PF_RUN(pf_shard_update_shared(p, buf, u2_local, stream));
   }
-  if (n_iter > 0) {
-    // flush: the last iteration's sum u^2, reduced in the (free) last slot of buf — u2_local keeps the LOCAL sum,
-    // the next chunk's first all-reduce carries it again
-    float* slot = buf + n - 1;
-    if (hipMemcpyAsync(slot, u2_local, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-      return comm_fail(PF_ERR_HIP, "pf_shard_iterations", "hipMemcpyAsync failed");
-    PF_RUN(all_reduce(c, slot, 1, s));
-    PF_RUN(pf_shard_flush(p, slot, stream));
+  return n_iter > 0 ? shard_flush(p, c, buf, n, u2_local, s) : PF_OK;
+}
+
+// The same iterations with whole multiples of `iters_per_graph` replayed from a graph that holds the kernels AND the
+// collective (pf_shard_graph_create), the remainder launched as above, then the flush.
+int pf_shard_iterations_graph(const pf_problem* p, void* comm, void* graph, int iters_per_graph, int n_iter, float* buf,
+                              float* u2_local, void* stream) {
+  if (!graph || iters_per_graph < 1) return comm_fail(PF_ERR_ARG, "pf_shard_iterations_graph", "bad argument");
+  if (!p || !comm || !buf || !u2_local || n_iter < 0) return comm_fail(PF_ERR_ARG, "pf_shard_iterations_graph", "bad argument");
+  pf_comm* c = (pf_comm*)comm;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)p->n_iface + (size_t)p->n_theta_active + 3;
+  int left = n_iter;
+  for (; left >= iters_per_graph; left -= iters_per_graph) PF_RUN(pf_graph_launch(graph, stream));
+  for (; left > 0; --left) {
+    PF_RUN(pf_shard_forward(p, stream));
+    PF_RUN(pf_shard_backward(p, buf, u2_local, stream));
+    PF_RUN(pf_shard_update_interior(p, stream));
+    PF_RUN(all_reduce(c, buf, n, s));
+    PF_RUN(pf_shard_update_shared(p, buf, u2_local, stream));
   }
-  return PF_OK;
+  return n_iter > 0 ? shard_flush(p, c, buf, n, u2_local, s) : PF_OK;
+}
+
+// iters_per_graph sharded iterations, collective included, as one hipGraph (handle for pf_graph_destroy).  It bakes in
+// *p, buf, u2_local and the communicator.  Every rank must create and replay it alike (the collective is inside).
+int pf_shard_graph_create(const pf_problem* p, void* comm, int iters_per_graph, float* buf, float* u2_local, void* stream,
+                          void** graph_out) {
+  if (!comm) return comm_fail(PF_ERR_ARG, "pf_shard_graph_create", "null communicator");
+  return pf_shard_graph_capture(p, iters_per_graph, buf, u2_local, (hipStream_t)stream,
+                                [](void* ctx, float* b, size_t n, hipStream_t s) { return all_reduce((pf_comm*)ctx, b, n, s); },
+                                comm, graph_out);
 }
 
 }  // extern "C"

@@ -278,3 +278,6 @@ inline int pf_net32_bucket(int width) {
 
 void pf_set_error(const char* msg);
 
+// pf_api.hip: `iters` sharded iterations as one hipGraph with the caller's collective captured inside (pf_comm.hip)
+int pf_shard_graph_capture(const pf_problem* p, int iters, float* buf, float* u2_local, hipStream_t stream,
+                           int (*all_reduce)(void* ctx, float* buf, size_t n, hipStream_t s), void* ctx, void** graph_out);

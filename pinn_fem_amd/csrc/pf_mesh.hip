@@ -492,6 +492,34 @@ __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node
   const float bc2s = P.state->bc2_sqrt;
   const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
   const float eps = (float)P.eps;
+  // Three independent pieces of latency-bound work; they start from opposite ends of the block (theta from thread 0 up,
+  // the interface dofs from the last thread down, the partial sums' loads first of all), so that for the usual sizes
+  // different waves carry them and their global round trips overlap instead of queueing behind each other.
+  double c = 0.0;
+  for (int i = threadIdx.x; i < nb_node; i += blockDim.x) c += (double)P.partials[PF_PART_U2 + i];
+  {
+    const float step_size = P.state->step_size_u;
+    for (int k = (int)blockDim.x - 1 - (int)threadIdx.x; k < P.n_shared; k += blockDim.x) {
+      const int dof = P.shared_dofs[k];
+      const unsigned fl = M.dof_flags[dof];
+      float uo = P.u[dof];
+      if (fl & PF_DOF_FIXED) {
+        if (uo != 0.f) P.u[dof] = 0.f;
+        continue;
+      }
+      const float gu = buf2[P.shared_slot[k]];
+      float m = P.m_u[dof], v = P.v_u[dof];
+      m = m + b1w * (gu - m);
+      v = v * b2;
+      v = v + (b2w * gu) * gu;
+      const float denom = sqrtf(v) / bc2s + eps;
+      uo = uo + (-step_size) * (m / denom);
+      if (!(fl & PF_DOF_GHOST)) c += (double)(uo * uo);
+      P.m_u[dof] = m;
+      P.v_u[dof] = v;
+      P.u[dof] = uo;
+    }
+  }
   {
     const float step_size = P.state->step_size_t;
     for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
@@ -513,31 +541,6 @@ __global__ __launch_bounds__(1024) void k_shard_update(pf_problem P, int nb_node
     __syncthreads();
     pack_net_ops(P, new_theta);
   }
-  double c = 0.0;
-  {
-    const float step_size = P.state->step_size_u;
-    for (int k = threadIdx.x; k < P.n_shared; k += blockDim.x) {
-      const int dof = P.shared_dofs[k];
-      const unsigned fl = M.dof_flags[dof];
-      float uo = P.u[dof];
-      if (fl & PF_DOF_FIXED) {
-        if (uo != 0.f) P.u[dof] = 0.f;
-        continue;
-      }
-      const float gu = buf2[P.shared_slot[k]];
-      float m = P.m_u[dof], v = P.v_u[dof];
-      m = m + b1w * (gu - m);
-      v = v * b2;
-      v = v + (b2w * gu) * gu;
-      const float denom = sqrtf(v) / bc2s + eps;
-      uo = uo + (-step_size) * (m / denom);
-      if (!(fl & PF_DOF_GHOST)) c += (double)(uo * uo);
-      P.m_u[dof] = m;
-      P.v_u[dof] = v;
-      P.u[dof] = uo;
-    }
-  }
-  for (int i = threadIdx.x; i < nb_node; i += blockDim.x) c += (double)P.partials[PF_PART_U2 + i];
   const double tc = pf_block_sum_d(c, dred);
   if (threadIdx.x == 0) sums3[0] = (float)tc;
   // the iteration's bookkeeping from the reduced sums, in the same block (one launch less per sharded iteration):

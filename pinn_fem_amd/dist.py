@@ -316,9 +316,16 @@ def run_iterations(backend: ShardBackend, n_iter: int, group=None,
     if n_iter > 0:
         backend.driver_used = "c-rccl" if comm is not None else "python"
     if comm is not None:
+        graph = backend.shard_graph(comm, bufs, group) if hasattr(backend, "shard_graph") else None
         with eng.on_stream():
-            _capi.check(eng.lib.pf_shard_iterations(eng._ref(), comm, int(n_iter), bufs[0].data_ptr(),
-                                                    bufs[1].data_ptr(), eng._stream()), "pf_shard_iterations")
+            if graph is not None:
+                _capi.check(eng.lib.pf_shard_iterations_graph(eng._ref(), comm, graph, backend.SHARD_GRAPH_ITERS,
+                                                              int(n_iter), bufs[0].data_ptr(), bufs[1].data_ptr(),
+                                                              eng._stream()), "pf_shard_iterations_graph")
+            else:
+                _capi.check(eng.lib.pf_shard_iterations(eng._ref(), comm, int(n_iter), bufs[0].data_ptr(),
+                                                        bufs[1].data_ptr(), eng._stream()), "pf_shard_iterations")
+        backend.driver_used = "c-rccl" + ("+graph" if graph is not None else "")
         return bufs
     ctx = eng.on_stream() if eng is not None else contextlib.nullcontext()
     with ctx:   # kernels and collectives on one stream (the engine's)
@@ -375,6 +382,54 @@ class HipShardBackend(ShardBackend):
         self.eng.P.grad_theta = self.bufs[0].data_ptr() + 4 * self.n_iface
         self.bufs[0].zero_()
         self.bufs[1].zero_()
+        self._drop_shard_graph()                 # it holds the previous pf_problem record by value
+
+    # -- whole sharded iterations (kernels + the collective) as one hipGraph, C driver only -------------
+    SHARD_GRAPH_ITERS = int(os.environ.get("PINNFEM_SHARD_GRAPH_ITERS", 10))
+    _sgraph = None          # None: not tried yet for this begin(); False: unavailable; else the handle
+    graph_creates = 0
+
+    def _drop_shard_graph(self):
+        if self._sgraph:
+            self.eng.lib.pf_graph_destroy(self._sgraph)
+        self._sgraph = None
+
+    def shard_graph(self, comm, bufs=None, group=None):
+        """Handle of pf_shard_graph_create for the current begin(), or None (not switched on, foreign buffers, or the
+        capture failed on ANY rank — decided collectively, the collective is inside the graph).
+        OPT-IN (PINNFEM_SHARD_GRAPH=1): on this pool the path can only be exercised on an RCCL group of ONE rank,
+        where ncclAllReduce short-cuts and RCCL's graph-capture machinery is not entered at all; there it is
+        bit-identical to the eager driver and 7 % faster (0.1835 vs 0.197 ms per iteration at 10^6 elements).  Until it
+        has run on a multi-GPU node the default stays the eager C driver."""
+        import ctypes as C
+        if comm is None or os.environ.get("PINNFEM_SHARD_GRAPH", "0") != "1":
+            return None
+        if bufs is not None and (bufs[0].data_ptr() != self.bufs[0].data_ptr() or
+                                 bufs[1].data_ptr() != self.bufs[1].data_ptr()):
+            return None
+        if self._sgraph is None:
+            e = self.eng
+            g = C.c_void_p()
+            with e.on_stream():
+                rc = e.lib.pf_shard_graph_create(e._ref(), comm, self.SHARD_GRAPH_ITERS, self.bufs[0].data_ptr(),
+                                                 self.bufs[1].data_ptr(), e._stream(), C.byref(g))
+            ok = torch.tensor([1 if rc == 0 and g.value else 0], dtype=torch.int32, device=self.device)
+            if dist.is_initialized():
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 1:
+                self._sgraph = g
+                self.graph_creates += 1
+            else:
+                if rc == 0 and g.value:
+                    e.lib.pf_graph_destroy(g)
+                self._sgraph = False
+        return self._sgraph or None
+
+    def __del__(self):
+        try:
+            self._drop_shard_graph()
+        except Exception:
+            pass
 
     def state(self):
         return self.eng.state()
@@ -541,7 +596,8 @@ class ShardedChainEngine:
     def prepare(self):
         """Create the C driver's RCCL communicator (collective) ahead of the first iteration."""
         comm = rccl_comm(self.backend)
-        self.backend.driver_used = "c-rccl" if comm is not None else "python"
+        graph = self.backend.shard_graph(comm) if comm is not None else None     # captured now, never inside a timed region
+        self.backend.driver_used = ("c-rccl" + ("+graph" if graph is not None else "")) if comm is not None else "python"
 
     def iterate(self, n):
         run_iterations(self.backend, n, bufs=self.bufs)

@@ -679,8 +679,9 @@ def test_cli_under_torchrun_unseeded_ranks_share_rank0_theta(tmp_path):
 
 def test_sharded_c_driver_real_rccl_world1():
     """The product's multi-GPU driver (pf_shard_iterations: kernels + ncclAllReduce from one C loop on an own
-    RCCL communicator) and the torch.distributed driver, both on a real RCCL process group of ONE rank (all
-    this box offers): bit-identical to the single-engine path after 40 iterations on a 20000-element chain."""
+    RCCL communicator), its opt-in hipGraph form (pf_shard_iterations_graph: the collective captured inside) and the
+    torch.distributed driver, all on a real RCCL process group of ONE rank (all this box offers): bit-identical to
+    the single-engine path after 40 iterations on a 20000-element chain."""
     import subprocess
     import sys
     from helpers import ROOT
@@ -692,7 +693,9 @@ def test_sharded_c_driver_real_rccl_world1():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     got = json.loads(line)
     assert got["iters"] == [40, 40]
-    assert got["rel_err_u"] == 0.0 and got["rel_err_theta"] == 0.0, got
+    assert got["rel_err_u"] == 0.0 and got["rel_err_theta"] == 0.0, got          # all three drivers, bit for bit
+    # the opt-in form with whole iterations (collective included) replayed from a hipGraph really ran
+    assert got["driver_used_c"] == "c-rccl" and got["driver_used_c+graph"] == "c-rccl+graph", got
 
 
 # ---- classical Newton-Raphson on the device ------------------------------------

@@ -33,10 +33,12 @@ def main():
     cfg = SolverConfig(max_iterations=10 + steps, tolerance=0.0, learning_rate_u=0.01,
                        learning_rate_theta=5e-4, alpha_physics=1.0, alpha_data=100.0)
     out, res = {}, {}
-    for drv in ("python", "c"):
-        os.environ["PINNFEM_SHARD_DRIVER"] = drv
+    for drv in ("python", "c", "c+graph"):
+        os.environ["PINNFEM_SHARD_DRIVER"] = drv.split("+")[0]
+        os.environ["PINNFEM_SHARD_GRAPH"] = "1" if drv.endswith("graph") else "0"
         sh = ShardedChainEngine(n, "ex4", 0, 1, dev)
         sh.begin(None, 0.1, cfg)
+        sh.prepare()
         sh.iterate(10)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -45,6 +47,7 @@ def main():
         torch.cuda.synchronize()
         out["sharded_ms_per_iter_%s_driver" % drv] = (time.perf_counter() - t0) / steps * 1e3
         out["host_enqueue_ms_per_iter_%s_driver" % drv] = (t1 - t0) / steps * 1e3
+        out["driver_used_%s" % drv] = sh.backend.driver_used
         res[drv] = (sh.backend.eng.u.cpu().numpy(), sh.backend.eng.theta.flat.cpu().numpy(), int(sh.state().iter))
     model, mv, md, _ = build_model(n, "ex4")
     eng = HipEngine(model, mv, md, device=dev)
