@@ -235,15 +235,13 @@ __device__ __forceinline__ void load_wo(const unsigned char* __restrict__ img, i
 template <int IN>
 __device__ __forceinline__ float layer1_row(const float4& w, const float (&x)[3]) {
   // layer 1 on the vector ALU in float, the reference's order: bias, then the inputs ascending
-  float c;
+  float c;                 // (the bias itself: fma(b, 1, 0) would only turn a -0.0 bias into +0.0)
   if constexpr (IN == 3) {
-    c = fmaf(w.w, 1.0f, 0.f);
-    c = fmaf(w.x, x[0], c);
+    c = fmaf(w.x, x[0], w.w);
     c = fmaf(w.y, x[1], c);
     c = fmaf(w.z, x[2], c);
   } else {
-    c = fmaf(w.z, 1.0f, 0.f);
-    c = fmaf(w.x, x[0], c);
+    c = fmaf(w.x, x[0], w.z);
     c = fmaf(w.y, x[1], c);
   }
   return c;
