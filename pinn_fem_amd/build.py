@@ -29,15 +29,19 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.j
 
 
 def _sources():
-    units = [("pf_api.o", "pf_api.hip", []), ("pf_mesh.o", "pf_mesh.hip", []), ("pf_comm.o", "pf_comm.hip", []), ("pf_pcg.o", "pf_pcg.hip", [])]
+    units = [("pf_api.o", "pf_api.hip", []), ("pf_mesh.o", "pf_mesh.hip", ["-fno-slp-vectorize"]),
+             ("pf_comm.o", "pf_comm.hip", []), ("pf_pcg.o", "pf_pcg.hip", [])]
     # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
     # removes the v_accvgpr_read copies in front of every tanh
     units += [(f"pf_net44_{w}.o", "pf_net44.hip", [f"-DPF_HP={w}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
               for w in reversed(WIDTHS)]
-    units += [(f"pf_net32_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
-              for r in reversed(NR_BUCKETS)]
-    units += [(f"pf_net32b_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}", "-DPF_PREC=1", "-mllvm", "-amdgpu-mfma-vgpr-form=1"])
-              for r in reversed(NR_BUCKETS)]
+    # -fno-slp-vectorize: left on, the SLP vectoriser pairs the kernels' independent fma / mul chains into v_pk_fma_f32 /
+    # v_pk_mul_f32, which issue SLOWER than the two scalar instructions they replace on gfx950 (6.6 against 2 x 1.4 cycles
+    # per SIMD, tools/valu_rate2.hip) and need register-pair shuffling on top (100 v_mov per 64 elements in the forward
+    # kernel, 31 without); registers per lane drop from 108 to 95
+    n32 = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+    units += [(f"pf_net32_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}"] + n32) for r in reversed(NR_BUCKETS)]
+    units += [(f"pf_net32b_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}", "-DPF_PREC=1"] + n32) for r in reversed(NR_BUCKETS)]
     units += [(f"pf_net_{w}.o", "pf_net.hip", [f"-DPF_HP={w}"]) for w in WIDTHS]
     return units
 
