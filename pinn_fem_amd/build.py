@@ -40,6 +40,8 @@ def _sources():
     # per SIMD, tools/valu_rate2.hip) and need register-pair shuffling on top (100 v_mov per 64 elements in the forward
     # kernel, 31 without); registers per lane drop from 108 to 95
     n32 = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+    if os.environ.get("PINNFEM_N32_DBG", "0") == "1":       # timing-experiment build: the PF_N32_DBG knobs are live
+        n32.append("-DPF_N32_DBG_ENABLE=1")
     units += [(f"pf_net32_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}"] + n32) for r in reversed(NR_BUCKETS)]
     units += [(f"pf_net32b_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}", "-DPF_PREC=1"] + n32) for r in reversed(NR_BUCKETS)]
     units += [(f"pf_net_{w}.o", "pf_net.hip", [f"-DPF_HP={w}"]) for w in WIDTHS]

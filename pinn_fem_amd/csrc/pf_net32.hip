@@ -37,6 +37,13 @@
 #ifndef PF_PREC
 #define PF_PREC 0
 #endif
+// Timing-experiment knobs (PF_N32_DBG bits: skip gradient tiles / back-propagation / transcendentals / MFMAs / barriers,
+// time stamps) exist only in builds with -DPF_N32_DBG_ENABLE=1 (PINNFEM_N32_DBG=1 python -m pinn_fem_amd.build): as
+// run-time branches in the task loop they split it into basic blocks, and the s_waitcnt the compiler must then place at
+// every join made the product kernels wait for LDS reads they did not need yet.
+#ifndef PF_N32_DBG_ENABLE
+#define PF_N32_DBG_ENABLE 0
+#endif
 #define PF_CAT2(a, b) a##b
 #define PF_CAT(a, b) PF_CAT2(a, b)
 
@@ -394,7 +401,8 @@ __device__ __forceinline__ void copy_image(unsigned char* dst, const unsigned ch
 constexpr int FW_THREADS = 1024;
 
 template <int L, int IN>
-__global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg, int ws) {
+__global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg_arg, int ws) {
+  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
   extern __shared__ __align__(16) unsigned char smem[];
   const pf_net net = P.net[which];
   copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), pf_n32_bytes(L));
@@ -609,19 +617,16 @@ __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ 
       if constexpr (Q < NPR) split_pair(d[2 * Q], d[2 * Q + 1], dhi[Q], dlo[Q]);
       else { dhi[Q] = 0u; dlo[Q] = 0u; }
     });
-    // back-propagation to layer LL-1 first: it is the critical path (d_{LL-1} feeds the next layer)
+    // Order of issue (a wave issues in order, so this order IS the overlap): the LDS writes of the gradient tile's
+    // operands, the weights and ALL transposed reads, then the back-propagation products — whose 6 x 32 matrix cycles
+    // cover the LDS write -> transposed read latency — and only then the tile products that consume the reads.
+    // (Back-propagation first and the LDS round trip after it left ~200-300 cycles exposed per layer and tile.)
     f32x16 acc = zero16();
-    if constexpr (LL >= 2) {
-      LayerW w;
-      load_layer<LL, true>(img, lane, w);
-      sfor<0, KS>([&](auto ks) {
-        constexpr int S = ks;
-        acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
-                    as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
-      });
-    }
-    // gradient tile of layer LL: rows d_LL through LDS; columns a_{LL-1} (LL >= 2) or the inputs (LL == 1)
+    LayerW w;
+    if constexpr (LL >= 2) load_layer<LL, true>(img, lane, w);
+    h8 ahi[2], alo[2], bhi[2], blo[2];
     if (!(dbg & 1)) {
+      // gradient tile of layer LL: rows d_LL through LDS; columns a_{LL-1} (LL >= 2) or the inputs (LL == 1)
       write_rows<0, 0>(wb, lane, dhi);
       if constexpr (!BF) write_rows<0, 1>(wb, lane, dlo);
       if constexpr (LL >= 2) {
@@ -645,11 +650,24 @@ __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ 
       if constexpr (LL == 1 && COMPACT) rdb = ((lane & 3) == 3) ? rd - REGION : rd;
       sfor<0, 2>([&](auto ks) {
         constexpr int S = ks;
-        const h8 ahi = read_operand<0>(rd, S), bhi = read_operand<REGION>(rdb, S);
-        h8 alo = ahi, blo = bhi;     // (unused with plain bf16 operands)
-        if constexpr (!BF) { alo = read_operand<SP_STRIDE>(rd, S); blo = read_operand<REGION + SP_STRIDE>(rd, S); }
-        T[LL - 1] = mfma3(T[LL - 1], ahi, alo, bhi, blo);
+        ahi[S] = read_operand<0>(rd, S);
+        bhi[S] = read_operand<REGION>(rdb, S);
+        alo[S] = ahi[S]; blo[S] = bhi[S];     // (unused with plain bf16 operands)
+        if constexpr (!BF) { alo[S] = read_operand<SP_STRIDE>(rd, S); blo[S] = read_operand<REGION + SP_STRIDE>(rd, S); }
       });
+      PF_STAGE();
+    }
+    // back-propagation to layer LL-1
+    if constexpr (LL >= 2) {
+      sfor<0, KS>([&](auto ks) {
+        constexpr int S = ks;
+        acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
+                    as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
+      });
+    }
+    if (!(dbg & 1)) {
+      PF_STAGE();
+      sfor<0, 2>([&](auto ks) { constexpr int S = ks; T[LL - 1] = mfma3(T[LL - 1], ahi[S], alo[S], bhi[S], blo[S]); });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -663,7 +681,8 @@ __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ 
 // GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the other net's
 // backward.  Partial gradient row of the block: the padded image of pf_common.h (what theta_stage1 sums).
 template <int L, int IN, bool GEA>
-__global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_problem P, int which, int hp, int dbg) {
+__global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_problem P, int which, int hp, int dbg_arg) {
+  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int DIM = IN - 1;
   constexpr int IMG = pf_n32_bytes(L);
