@@ -548,15 +548,18 @@ struct TaskIn {
   float ui[2], uj[2], gi[2], gj[2];
 };
 
+// with_nn: also load the element's node ids (the main loop has them already: they are fetched TWO tasks ahead, so that
+// the nodal gathers of task_fetch_b, which need them as addresses, never wait for a load issued in the same iteration)
 template <int IN, bool GEA>
 __device__ __forceinline__ void task_fetch_a(TaskIn<IN - 1>& t, const pf_problem& P, const pf_net& onet,
-                                             const float* __restrict__ other, const float* __restrict__ mine, int e) {
+                                             const float* __restrict__ other, const float* __restrict__ mine, int e,
+                                             bool with_nn = true) {
   load_x<IN>(t.x, P, e);
   t.oth = onet.enabled ? other[e] : onet.scale;
   t.own = mine[e];
   t.gea = 0.f;
   if (GEA) {
-    t.nn = reinterpret_cast<const int2*>(P.mesh.conn)[e];
+    if (with_nn) t.nn = reinterpret_cast<const int2*>(P.mesh.conn)[e];
     t.g = load_geo(P.mesh.egeo, e);
   } else {
     t.nn = int2{0, 0};
@@ -710,7 +713,11 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
   const int stride = gridDim.x * waves * 64;
   int base = (blockIdx.x * waves + wv) * 64;
   TaskIn<DIM> nxt;
-  if (n > 0) task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(base + lane, n - 1));
+  int2 nn_ahead = int2{0, 0};                    // node ids of the task after next (GEA only)
+  if (n > 0) {
+    task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(base + lane, n - 1));
+    if (GEA) nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(base + stride + lane, n - 1)];
+  }
   __syncthreads();
   if (P.state->done != 0 || n <= 0) return;      // block-uniform
   task_fetch_b<IN, GEA>(nxt, P);
@@ -731,7 +738,16 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
     const bool live = e < n;
     const TaskIn<DIM> cur = nxt;
     const bool more = base + stride < n;
-    if (more) task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(e + stride, n - 1));
+    if (more) {
+      // the next task's inputs: its node ids are already here, so its nodal gathers leave in the same breath; the ids
+      // of the task after it start their trip now
+      task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(e + stride, n - 1), false);
+      if (GEA) {
+        nxt.nn = nn_ahead;
+        task_fetch_b<IN, GEA>(nxt, P);
+        nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(e + 2 * stride, n - 1)];
+      }
+    }
     // ---- per-element scalars: one element per lane ----------------------------------------------------------
     // softplus'(z) = sigmoid(z) = 1 - exp(-softplus(z)) from the forward's stored value (= softplus(z) * scale), so the
     // output unit need not be recomputed (torch: z > 20 ? 1 : e^z / (e^z + 1), the same number to float round-off)
@@ -748,7 +764,6 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
       g = g * net.scale;         // output*scale backward              (properties.py:156)
       gz = net.positive ? g * (-expm1f(-(cur.own * inv_scale))) : g;
     }
-    if (more) task_fetch_b<IN, GEA>(nxt, P);
     // power-of-two scale: max |d| S <= 2^14 with the weight bound of the image header; S only ever falls, T follows
     {
       const float gmax = wave_max(fabsf(gz)) * bound;
