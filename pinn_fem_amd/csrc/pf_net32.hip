@@ -415,7 +415,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
   const int rounds = (ntasks + per_round - 1) / per_round;        // block-uniform trip count: equal barrier counts
   int task = blockIdx.x * waves + wv;
   float xn[3];
-  if (n > 0) load_x<IN>(xn, P, min(task * 64 + lane, n - 1));
+  // ws: this launch also writes the element stiffness from both properties: the other property and the element length
+  // travel with the coordinates, one round ahead (loaded where they are used they cost a global round trip per round)
+  const pf_net onet = P.net[1 - which];
+  const float* __restrict__ oprop = which == 0 ? P.prop_a : P.prop_e;
+  float on = onet.scale, l0n = 1.0f;
+  if (n > 0) {
+    const int e0 = min(task * 64 + lane, n - 1);
+    load_x<IN>(xn, P, e0);
+    if (ws) {
+      if (onet.enabled) on = oprop[e0];
+      l0n = P.mesh.egeo[4 * (size_t)e0 + 3];
+    }
+  }
   __syncthreads();
   if (P.state->done || n <= 0) return;
   const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
@@ -426,7 +438,15 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
     const int e = task * 64 + lane;
     float x0[3], x1[3];
     sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
-    if (r + 1 < rounds) load_x<IN>(xn, P, min(e + per_round * 64, n - 1));
+    const float o = on, l0 = l0n;
+    if (r + 1 < rounds) {
+      const int en = min(e + per_round * 64, n - 1);
+      load_x<IN>(xn, P, en);
+      if (ws) {
+        if (onet.enabled) on = oprop[en];
+        l0n = P.mesh.egeo[4 * (size_t)en + 3];
+      }
+    }
     TileAct<L, false> A0, A1;
     float p0, p1;
     forward_tiles<L, IN, false>(smem, lane, x0, x1, A0, A1, p0, p1, dbg, grp);
@@ -434,12 +454,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
     if (e < n) {
       const float v = (net.positive ? pf_softplus(z) : z) * net.scale;
       out[e] = v;
-      if (ws) {   // element stiffness for the node kernels: (young * area) / l0, nn_assembly.py:74 (2-D), :37 (1-D)
-        const pf_net onet = P.net[1 - which];
-        const float o = onet.enabled ? (which == 0 ? P.prop_a : P.prop_e)[e] : onet.scale;
-        const float l0 = P.mesh.egeo[4 * (size_t)e + 3];
-        P.elem_s[e] = (which == 0 ? v * o : o * v) / l0;
-      }
+      // element stiffness for the node kernels: (young * area) / l0, nn_assembly.py:74 (2-D), :37 (1-D)
+      if (ws) P.elem_s[e] = (which == 0 ? v * o : o * v) / l0;
     }
     if (grp == 3) __builtin_amdgcn_s_barrier();
   }
