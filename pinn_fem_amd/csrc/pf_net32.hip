@@ -667,29 +667,42 @@ __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ 
       // lanes that read column quad 12..15 take the ZERO block (their base, as it is) instead of the bias block
       const unsigned char* rdb = rd;
       if constexpr (LL == 1 && COMPACT) rdb = ((lane & 3) == 3) ? rd - REGION : rd;
-      sfor<0, 2>([&](auto ks) {
-        constexpr int S = ks;
-        ahi[S] = read_operand<0>(rd, S);
-        bhi[S] = read_operand<REGION>(rdb, S);
-        alo[S] = ahi[S]; blo[S] = bhi[S];     // (unused with plain bf16 operands)
-        if constexpr (!BF) { alo[S] = read_operand<SP_STRIDE>(rd, S); blo[S] = read_operand<REGION + SP_STRIDE>(rd, S); }
-      });
-      PF_STAGE();
-    }
-    // back-propagation to layer LL-1
-    if constexpr (LL >= 2) {
-      sfor<0, KS>([&](auto ks) {
-        constexpr int S = ks;
-        acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
-                    as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
-      });
-    }
-    if (!(dbg & 1)) {
+      auto read_all = [&]() {
+        sfor<0, 2>([&](auto ks) {
+          constexpr int S = ks;
+          ahi[S] = read_operand<0>(rd, S);
+          bhi[S] = read_operand<REGION>(rdb, S);
+          alo[S] = ahi[S]; blo[S] = bhi[S];     // (unused with plain bf16 operands)
+          if constexpr (!BF) { alo[S] = read_operand<SP_STRIDE>(rd, S); blo[S] = read_operand<REGION + SP_STRIDE>(rd, S); }
+        });
+      };
+      // (the wide layout with three hidden layers has no registers left for 16 reads in flight across the products:
+      //  there the reads follow the back-propagation, as they used to)
+      constexpr bool EARLY = COMPACT || L < 3;
+      if constexpr (EARLY) {
+        read_all();
+        PF_STAGE();
+      }
+      // back-propagation to layer LL-1
+      if constexpr (LL >= 2) {
+        sfor<0, KS>([&](auto ks) {
+          constexpr int S = ks;
+          acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
+                      as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
+        });
+      }
+      if constexpr (!EARLY) read_all();
       PF_STAGE();
       sfor<0, 2>([&](auto ks) { constexpr int S = ks; T[LL - 1] = mfma3(T[LL - 1], ahi[S], alo[S], bhi[S], blo[S]); });
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else if constexpr (LL >= 2) {     // (timing build with the gradient tiles switched off)
+      sfor<0, KS>([&](auto ks) {
+        constexpr int S = ks;
+        acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
+                    as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
+      });
     }
     if constexpr (LL >= 2) {
       sfor<0, NR>([&](auto r) { constexpr int R = r; d[R] = acc[R] * A.t[LL - 2][R]; });
