@@ -3,7 +3,8 @@ network materials the "NR" phase of solve_hybrid is GD again, FEM/python/fem/sol
 matrix products in float32-grade arithmetic (2-way split f16 operands, the default) and in plain bf16 (f32
 accumulate), same initial parameters.  Reports per run: iterations per load increment, converged flag, final
 residual norm and loss, and the deviation of the bf16 run from the float32 run in displacements and identified E*A
-at the element centroids; plus the fixed-iteration throughput of both variants on the 10^6-element ex4-shape chain.
+at the element centroids; plus the fixed-iteration throughput of both variants on the 10^6-element ex4-shape chain
+and, on that chain, how far bf16 operands move one evaluation of properties, residual and gradients.
     python tools/bf16_study.py [out.json]"""
 import json, os, sys, time
 import numpy as np, torch
@@ -78,6 +79,30 @@ def throughput(dtype, n=1_000_000, steps=50):
         best = min(best, (time.perf_counter() - t0) / steps)
     return dict(dtype=dtype, n_elems=n, ms_per_iteration=best * 1e3, evals_per_s=n / best)
 
+def at_scale(n=1_000_000):
+    """One evaluation of losses and gradients on the 10^6-element ex4-shape chain (the bench's mesh) from the same
+    state with both operand types: how far plain bf16 operands move the properties (forward), the residual and the
+    gradients (backward) — the per-iteration perturbation behind the run-level differences above."""
+    from bench import build_model
+    from pinn_fem_amd.engine import HipEngine
+    x = np.arange(n + 1, dtype=np.float64)
+    u = np.zeros(2 * (n + 1), dtype=np.float32)
+    u[0::2] = (1e-3 * x * (1.0 + 0.05 * np.sin(x / 50.0))).astype(np.float32)
+    res = {}
+    for dtype in ("f32", "bf16"):
+        torch.manual_seed(0)
+        model, mv, mdofs, _ = build_model(n, "ex4")
+        eng = HipEngine(model, mv, mdofs, mlp_dtype=dtype, fe_mode=1)
+        losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.6)
+        res[dtype] = dict(losses=losses, gu=gu.cpu().numpy().copy(), gt=gt.cpu().numpy().copy(),
+                          e=eng.prop_e[:n].cpu().numpy().copy(), a=eng.prop_a[:n].cpu().numpy().copy())
+    f, b = res["f32"], res["bf16"]
+    return dict(n_elems=n, state="u_x = 1e-3 x (1 + 0.05 sin(x/50)), load factor 0.6, fe_mode delta",
+                bf16_vs_f32=dict(young=rel(b["e"], f["e"]), area=rel(b["a"], f["a"]),
+                                 loss_total=abs(b["losses"]["loss_total"] / f["losses"]["loss_total"] - 1.0),
+                                 residual_norm=abs(b["losses"]["residual_norm"] / f["losses"]["residual_norm"] - 1.0),
+                                 grad_u=rel(b["gu"], f["gu"]), grad_theta=rel(b["gt"], f["gt"])))
+
 def main():
     out = {"runs": [], "compare": [], "throughput": []}
     for ex in ("example7", "example7-P"):
@@ -90,6 +115,7 @@ def main():
             iterations=dict(reference=r32["ref_iterations"], f32=r32["iterations_total"], bf16=rbf["iterations_total"])))
     for dt in ("f32", "bf16"):
         out["throughput"].append(throughput(dt))
+    out["at_scale"] = at_scale()
     txt = json.dumps(out, indent=1)
     print(txt)
     if len(sys.argv) > 1:
