@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PF_ABI_VERSION 6
+#define PF_ABI_VERSION 7
 
 /* error codes */
 #define PF_OK 0
@@ -292,6 +292,10 @@ int pf_shard_flush(const pf_problem* p, const float* u2_reduced, void* stream);
 int pf_comm_unique_id(const char* librccl_path, void* id_out);
 int pf_comm_create(const char* librccl_path, const void* id, int rank, int world, void** comm_out);
 int pf_comm_destroy(void* comm);
+/* failure path: ncclCommAbort instead of ncclCommDestroy — does not wait for outstanding collectives, so a rank that
+ * raised can leave while its peers sit in (or it has itself enqueued) a collective that will never be matched.  Do not
+ * synchronise the device first. */
+int pf_comm_abort(void* comm);
 /* rank and rank count as the communicator reports them (ncclCommUserRank, ncclCommCount) */
 int pf_comm_info(void* comm, int* rank_out, int* nranks_out);
 /* sum over ranks of buf[0..n), in place, on `stream` (the collective pf_shard_iterations issues, on its own) */

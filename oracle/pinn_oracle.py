@@ -174,16 +174,23 @@ def mlp_forward(net: NetParams, x: np.ndarray):
     raise AssertionError
 
 
-def mlp_backward(net: NetParams, acts, g_z: np.ndarray) -> List[np.ndarray]:
-    """Gradients of sum_e g_z[e]*z_out[e] w.r.t. net.tensors (autograd of generic.py:141)."""
+def mlp_backward(net: NetParams, acts, g_z: np.ndarray, acc64: bool = False) -> List[np.ndarray]:
+    """Gradients of sum_e g_z[e]*z_out[e] w.r.t. net.tensors (autograd of generic.py:141).
+    acc64: the sums over ELEMENTS are accumulated in float64 (every per-element term is still the float32
+    value): a checker for large meshes whose own summation error is negligible, so that a comparison
+    measures the device kernel's error and not the order of a float32 sum over 10^6 terms."""
     nl = net.n_linear
     grads: List[Optional[np.ndarray]] = [None] * (2 * nl)
     g = g_z.reshape(-1, 1).astype(f32)                     # grad wrt pre-activation of layer l
     for l in range(nl - 1, -1, -1):
         w = net.tensors[2 * l].astype(f32)
         h_in = acts[l]
-        grads[2 * l] = (g.T @ h_in).astype(f32)
-        grads[2 * l + 1] = g.sum(axis=0, dtype=f32)
+        if acc64:
+            grads[2 * l] = (g.T.astype(np.float64) @ h_in.astype(np.float64)).astype(f32)
+            grads[2 * l + 1] = g.sum(axis=0, dtype=np.float64).astype(f32)
+        else:
+            grads[2 * l] = (g.T @ h_in).astype(f32)
+            grads[2 * l + 1] = g.sum(axis=0, dtype=f32)
         if l > 0:
             gh = (g @ w).astype(f32)
             g = (gh * (f32(1.0) - h_in * h_in)).astype(f32)   # tanh backward: g*(1-y*y)
@@ -263,7 +270,10 @@ def internal_force(geo: Geometry, s: np.ndarray, u: np.ndarray, ndof: int,
 
 def loss_and_grads(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
                    alpha_physics: float = 1.0, alpha_data: float = 100.0,
-                   want_grads: bool = True, fe_mode: str = "reference") -> StepOut:
+                   want_grads: bool = True, fe_mode: str = "reference", acc64: bool = False) -> StepOut:
+    """acc64: accumulate the sums over elements / dofs (loss terms, parameter gradients) in float64 — see
+    mlp_backward; per-element arithmetic stays float32."""
+    sdt = np.float64 if acc64 else f32
     u = u.astype(f32)
     ndof = pb.ndof
     free, fixed = free_and_fixed_dofs(ndof, pb.fixed_dofs)
@@ -271,19 +281,19 @@ def loss_and_grads(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
     f_int = internal_force(geo, s, u, ndof, fe_mode)
     f_ext = pb.loads.astype(f32)
     r = (f_int[free] - f32(lam) * f_ext[free]).astype(f32)         # solver.py:267-269
-    loss_p = f32(0.5) * np.sum(r * r, dtype=f32)                    # :270
+    loss_p = f32(0.5) * f32(np.sum(r * r, dtype=sdt))               # :270
     has_meas = pb.measured_vals is not None and pb.measured_dofs is not None
     use_data = has_meas and alpha_data > 0 and len(pb.measured_vals) > 0
     if use_data:
         mv = pb.measured_vals.astype(f32)
         md = pb.measured_dofs.astype(int)
         d = (mv - u[md]).astype(f32)                                # :274
-        loss_d = np.mean(d * d, dtype=f32)                          # :275
+        loss_d = f32(np.mean(d * d, dtype=sdt))                     # :275
         loss = f32(alpha_physics) * loss_p + f32(alpha_data) * loss_d   # :277-279
     else:
         loss_d = f32(0.0)
         loss = f32(alpha_physics) * loss_p                          # :283
-    rn = f32(np.sqrt(np.sum(r * r, dtype=f32)))                     # torch.norm :306
+    rn = f32(np.sqrt(np.sum(r * r, dtype=sdt)))                     # torch.norm :306
     grad_u = np.zeros(ndof, dtype=f32)
     grad_theta: List[Optional[np.ndarray]] = []
     if want_grads:
@@ -305,7 +315,7 @@ def loss_and_grads(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
                 z, acts = ctx
                 g_out = (g_ea * other * f32(prop.scale)).astype(f32)
                 g_z = (g_out * softplus_grad(z)).astype(f32) if prop.enforce_positive else g_out
-                grad_theta.extend(mlp_backward(prop, acts, g_z))
+                grad_theta.extend(mlp_backward(prop, acts, g_z, acc64))
         if isinstance(pb.density, NetParams):
             # never evaluated by the assembly: grad stays None (nn_assembly.py:207-208)
             grad_theta.extend([None] * len(pb.density.tensors))

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpinnfem_hip.so")
 
-PF_ABI_VERSION = 6
+PF_ABI_VERSION = 7
 PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
 PF_DOF_FIXED, PF_DOF_MEASURED, PF_DOF_SHARED, PF_DOF_GHOST = 1, 2, 4, 8
 PF_WG_SHUFFLE, PF_WG_MFMA, PF_WG_MFMA44, PF_WG_MFMA32 = 0, 1, 2, 3
@@ -129,6 +129,7 @@ SYMBOLS = {
     "pf_comm_unique_id": (C.c_int, [C.c_char_p, C.c_void_p]),
     "pf_comm_create": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "pf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "pf_comm_abort": (C.c_int, [C.c_void_p]),
     "pf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pf_comm_all_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "pf_shard_iterations": (C.c_int, [_PP, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

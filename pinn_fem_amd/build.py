@@ -82,9 +82,18 @@ def _newest_input(src):
     return max(os.path.getmtime(p) for p in paths)
 
 
+def _obj_path(unit):
+    """Object file of a unit; the unit's compile flags are part of the NAME, so an object built with another define set
+    (e.g. the PINNFEM_N32_DBG=1 timing build) is never mistaken for this one on its mtime alone."""
+    obj, _, defs = unit
+    tag = hashlib.sha256(repr((FLAGS[:4], defs)).encode()).hexdigest()[:10]
+    stem, ext = os.path.splitext(obj)
+    return os.path.join(OBJ, f"{stem}.{tag}{ext}")
+
+
 def _compile(unit):
     obj, src, defs = unit
-    out = os.path.join(OBJ, obj)
+    out = _obj_path(unit)
     if os.path.exists(out) and os.path.getmtime(out) >= _newest_input(src):
         return obj, 0, ""
     cmd = [HIPCC, *FLAGS, *defs, "-c", os.path.join(CSRC, src), "-o", out]
@@ -116,7 +125,7 @@ def _build_locked(force: bool, verbose: bool) -> str:
                 print(f"[{obj}] {log.strip()}", file=sys.stderr)
             if rc != 0:
                 raise RuntimeError(f"hipcc failed on {obj}:\n{log}")
-    objs = [os.path.join(OBJ, u[0]) for u in units]
+    objs = [_obj_path(u) for u in units]
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:

@@ -365,16 +365,21 @@ def _init_distributed():
 
 
 def _shutdown_distributed(failed: bool):
-    """Tear the sharded run down in order: device idle, the C driver's RCCL communicators, then torch's
-    process group.  After a rank-local failure the other ranks may sit in a collective this rank will
-    never join: abort the group (they fail fast) instead of a collective-free destroy that could hang."""
+    """Tear the sharded run down.  Clean exit: device idle, the C driver's RCCL communicators, then torch's process
+    group.  After a rank-local failure the other ranks may sit in — or this rank may already have enqueued — a
+    collective that will never be matched: NO device synchronisation then (it would never return); abort the C
+    driver's communicators and torch's backends first, skip the collective destroy, and let the process exit
+    non-zero so that the launcher ends the peers."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return
-    try:
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        if failed:
+    from ..dist import destroy_rccl_comms
+    if failed:
+        try:
+            destroy_rccl_comms(failed=True)
+        except Exception:
+            pass
+        try:
             pg = dist.distributed_c10d._get_default_group()
             for be_name in ("cuda", "cpu"):
                 try:
@@ -383,7 +388,12 @@ def _shutdown_distributed(failed: bool):
                         be.abort()
                 except Exception:
                     pass
-        from ..dist import destroy_rccl_comms
+        except Exception:
+            pass
+        return        # no destroy_process_group(): it is collective for some backends
+    try:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         destroy_rccl_comms()
     finally:
         try:

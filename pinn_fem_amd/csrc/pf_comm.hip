@@ -21,6 +21,7 @@ struct pf_comm {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   ncclResult_t (*CommDestroy)(ncclComm_t);
+  ncclResult_t (*CommAbort)(ncclComm_t);
   ncclResult_t (*CommCount)(const ncclComm_t, int*);
   ncclResult_t (*CommUserRank)(const ncclComm_t, int*);
   const char* (*GetErrorString)(ncclResult_t);
@@ -45,6 +46,7 @@ static int load_rccl(pf_comm* c, const char* path) {
   PF_SYM(CommInitRank, "ncclCommInitRank")
   PF_SYM(AllReduce, "ncclAllReduce")
   PF_SYM(CommDestroy, "ncclCommDestroy")
+  PF_SYM(CommAbort, "ncclCommAbort")
   PF_SYM(CommCount, "ncclCommCount")
   PF_SYM(CommUserRank, "ncclCommUserRank")
   PF_SYM(GetErrorString, "ncclGetErrorString")
@@ -102,6 +104,17 @@ int pf_comm_destroy(void* comm) {
   if (!comm) return PF_OK;
   pf_comm* c = (pf_comm*)comm;
   c->CommDestroy(c->comm);
+  delete c;
+  return PF_OK;
+}
+
+// After a rank-local failure: tear the communicator down WITHOUT waiting for outstanding collectives (ncclCommAbort);
+// peers blocked in a collective this rank will never join then fail instead of hanging.  Never synchronise the device
+// before this call: an unmatched collective already on the stream would never complete.
+int pf_comm_abort(void* comm) {
+  if (!comm) return PF_OK;
+  pf_comm* c = (pf_comm*)comm;
+  c->CommAbort(c->comm);
   delete c;
   return PF_OK;
 }

@@ -100,8 +100,13 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
     finalize_body(P, (int)gridDim.x - 1, 0, 0, nullptr, nullptr, 0, P.part_half ^ 1, nullptr, fin_prev == 2);
     return;
   }
-  if (P.state->done) return;
   __shared__ float red[16];
+  // the stop flag, ONE read per block: block 0 of this very launch (the previous iteration's bookkeeping) may be raising
+  // it while the other blocks start, and waves of a block that disagreed would part ways before the barriers below
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = P.state->done;
+  __syncthreads();
+  if (s_done) return;
   const pf_mesh& M = P.mesh;
   const int fp = fin_prev ? 1 : 0;     // (fin_prev is 1 or 2: ONE extra block either way)
   const int bid = (int)blockIdx.x - fp, nblk = (int)gridDim.x - fp;
@@ -448,7 +453,12 @@ __global__ __launch_bounds__(1024) void k_finalize(pf_problem P, int nb_node, in
 template <int DIM>
 __global__ __launch_bounds__(1024) void k_shard_pack(pf_problem P, int nb_node, float* __restrict__ buf2,
                                                      const float* __restrict__ u2_local) {
-  if (P.state->done) return;
+  if (P.state->done) {
+    // after the stop the remaining iterations of a chunk still all-reduce buf: zero it, or the stale sums would be
+    // multiplied by the world size every iteration and run to inf (harmless only while every consumer returns early)
+    for (int k = threadIdx.x; k < P.n_iface + P.n_theta_active + 3; k += blockDim.x) buf2[k] = 0.f;
+    return;
+  }
   __shared__ double dred[16];
   const pf_mesh& M = P.mesh;
   if (P.n_theta_active > 0) theta_stage2(P, 0, nullptr);

@@ -15,7 +15,16 @@
 #define PF_N32_KA 2048.0f          /* activations are carried as KA * tanh: lo = a' - f16(a') stays a normal f16 */
 #define PF_N32_KW 16.0f            /* forward weights as KW * w, backward (transposed) as KB * w */
 #define PF_N32_KB 16.0f
-#define PF_N32_KL 256.0f           /* load factor in the gradient tile */
+// load factor in the gradient tile: kl = 2^(14 - e) with |lam| = m 2^e, 0.5 <= m < 1, so that kl |lam| is in
+// [2^13, 2^14) whatever the load factor (NaN / inf / 0: 1)
+__host__ __device__ inline float pf_n32_lam_scale(float lam) {
+  const float a = lam < 0.f ? -lam : lam;
+  if (!(a > 0.f) || !(a < 3.0e38f)) return 1.0f;
+  int ex = 0;
+  (void)frexpf(a, &ex);
+  ex = ex < -100 ? -100 : ex;
+  return ldexpf(1.0f, 14 - ex);
+}
 
 // byte offsets inside one net's image (all multiples of 16)
 __host__ __device__ constexpr int pf_n32_off_w1() { return 16; }                       // [16 r][2 h] float4: w1[u][0..in-1], b1[u]

@@ -428,8 +428,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
       l0n = P.mesh.egeo[4 * (size_t)e0 + 3];
     }
   }
+  // the stop flag, one read per block (the bookkeeping that raises it may run beside this launch: a block whose waves
+  // disagreed would part ways before the lockstep barriers below)
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = P.state->done;
   __syncthreads();
-  if (P.state->done || n <= 0) return;
+  if (s_done || n <= 0) return;
   const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
   unsigned long long st0 = 0, sr0 = 0;
   if (dbg & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
@@ -747,14 +751,19 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
     task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(base + lane, n - 1));
     if (GEA) nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(base + stride + lane, n - 1)];
   }
+  __shared__ int s_done;                         // the stop flag, one read per block (block-uniform by construction)
+  if (threadIdx.x == 0) s_done = P.state->done;
   __syncthreads();
-  if (P.state->done != 0 || n <= 0) return;      // block-uniform
+  if (s_done != 0 || n <= 0) return;
   task_fetch_b<IN, GEA>(nxt, P);
 
   // block-uniform scalars: keep them in SGPRs (the kernel runs at its register budget)
   const float bound = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, reinterpret_cast<const float*>(smem)[0])));
   const float kx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_ldexpf(1.0f, P.coord_exp))));
   const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / net.scale)));
+  // scale of the load factor inside the f16 gradient products: the power of two with 2^13 <= kl |lam| < 2^14 (like the
+  // coordinates' kx; a fixed factor would overflow f16 for large |lam| and lose the lo part for small ones)
+  const float kl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pf_n32_lam_scale(P.lam))));
   f32x16 T[L];          // sum over this wave's tasks of S * (tile products); S = Srun, a power of two that only falls
   sfor<0, L>([&](auto l) { constexpr int LL = l; T[LL] = zero16(); });
   float Srun = 0.f;     // 0: not chosen yet
@@ -820,10 +829,10 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
     both_tiles(cur.x[2], xb0, xb1);
     // ---- the two tiles ------------------------------------------------------------------------------------------
     auto tile_backward = [&](const TileAct<L, true>& A, const float (&xt)[3], float gt) {
-      // inputs of the combined tile: (KL lam, kx x, kx y, 1) resp. (KL lam, kx x, 1, 0)
+      // inputs of the combined tile: (kl lam, kx x, kx y, 1) resp. (kl lam, kx x, 1, 0)
       unsigned xhi[NPK], xlo[NPK];
       sfor<2, NPK>([&](auto q) { constexpr int Q = q; xhi[Q] = 0u; xlo[Q] = 0u; });
-      split_pair(PF_N32_KL * xt[0], kx * xt[1], xhi[0], xlo[0]);
+      split_pair(kl * xt[0], kx * xt[1], xhi[0], xlo[0]);
       split_pair(IN == 3 ? kx * xt[2] : 1.0f, IN == 3 ? 1.0f : 0.f, xhi[1], xlo[1]);
       // (before backward_tile: a'_L is dead there, ten registers less at the kernel's pressure peak)
       sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = fmaf(gt, A.aL[R], go[R]); });
@@ -887,7 +896,7 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
         if (c == 15) dst = pf_pad_wh(hp, LL) + j * (hp + 4) + hp;                      // bias column
         else if ((c & 15) < NR && kk < W) dst = pf_pad_wh(hp, LL) + j * (hp + 4) + kk;
       } else {
-        if (c < IN) { dst = j * 4 + c; k *= c == 0 ? PF_N32_KL : kx; }
+        if (c < IN) { dst = j * 4 + c; k *= c == 0 ? kl : kx; }
         else if (c == IN) dst = j * 4 + IN;                                           // bias (input 1.0)
       }
       if (dst >= 0) prow[dst] = t / k;

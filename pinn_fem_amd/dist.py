@@ -73,7 +73,14 @@ def element_ranges(n_elems: int, world: int) -> List[Tuple[int, int]]:
 
 
 def partition_mesh(elements: np.ndarray, n_nodes: int, dim: int, rank: int, world: int) -> Shard:
-    """Deterministic on every rank (same inputs -> same interface numbering)."""
+    """Deterministic on every rank (same inputs -> same interface numbering).
+
+    LOCALITY REQUIREMENT: the cut is by contiguous ELEMENT-ID ranges, so the element numbering must be spatially local
+    (consecutive ids = neighbouring elements, as mesh generators and the synthetic chain / girder produce).  On a mesh
+    numbered at random the interface grows to most of the mesh: the per-iteration all-reduce then carries O(N) floats
+    and the single-block interface kernels (k_shard_pack / k_shard_update) become the critical path.  A warning is
+    issued when the interface exceeds 5 % of the dofs (and 4096 floats); renumber the elements (e.g. along a
+    space-filling curve or by reverse Cuthill-McKee) before sharding such a mesh."""
     elements = np.asarray(elements, dtype=np.int64)
     n_elems = elements.shape[0]
     ranges = element_ranges(n_elems, world)
@@ -92,6 +99,11 @@ def partition_mesh(elements: np.ndarray, n_nodes: int, dim: int, rank: int, worl
     if ring.any():
         iface[elements[ring].reshape(-1)] = True
     iface_nodes = np.flatnonzero(iface)
+    if rank == 0 and iface_nodes.size * dim > max(4096, 0.05 * n_nodes * dim):
+        import warnings
+        warnings.warn(f"sharding: the interface holds {iface_nodes.size * dim} of {n_nodes * dim} dofs — the element "
+                      "numbering is not spatially local; every iteration all-reduces that many floats and updates them "
+                      "in one block.  Renumber the elements before sharding (see partition_mesh).", RuntimeWarning)
     slot_of = -np.ones(n_nodes, dtype=np.int64)
     slot_of[iface_nodes] = np.arange(iface_nodes.size)
     lo, hi = ranges[rank]
@@ -293,13 +305,18 @@ def broadcast_theta(flat: torch.Tensor, group=None, check: bool = True):
             raise RuntimeError("theta differs between ranks after the broadcast")
 
 
-def destroy_rccl_comms():
-    """Release the C driver's communicators (call before torch.distributed.destroy_process_group)."""
+def destroy_rccl_comms(failed: bool = False):
+    """Release the C driver's communicators (call before torch.distributed.destroy_process_group).
+    failed=True (this rank raised): abort them instead — no device synchronisation and no ncclCommDestroy, both of
+    which would wait for a collective the peers will never match."""
     lib = _capi.load()
     for comm in list(_RCCL_COMMS.values()):
         if comm is not None:
-            torch.cuda.synchronize()
-            lib.pf_comm_destroy(comm)
+            if failed:
+                lib.pf_comm_abort(comm)
+            else:
+                torch.cuda.synchronize()
+                lib.pf_comm_destroy(comm)
     _RCCL_COMMS.clear()
 
 

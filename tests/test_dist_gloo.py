@@ -165,3 +165,38 @@ def test_partition_invariants_on_random_meshes():
             assert set(mine) <= touch[r]
             owners[mine] += 1
         assert np.all(owners[sorted(set().union(*touch))] == 1)
+
+
+def test_rank_failure_ends_the_job_quickly(tmp_path):
+    """when one rank raises mid-solve while its peer already waits in a collective, the failing
+    rank's shutdown (pinn_fem_amd.cli.generic._shutdown_distributed(failed=True): no device synchronisation, abort of
+    the communicators, no collective destroy) must let the process exit so that the launcher ends the job — the run
+    must END (non-zero) well within the timeout instead of hanging in a teardown that waits for the lost collective."""
+    import time
+    runner = tmp_path / "fail_rank.py"
+    runner.write_text(
+        "import os, sys, time, torch\n"
+        "import torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from pinn_fem_amd.cli import generic as g\n"
+        "dist.init_process_group('gloo')\n"
+        "rank = dist.get_rank()\n"
+        "t = torch.ones(4)\n"
+        "dist.all_reduce(t)                      # the group works\n"
+        "failed = True\n"
+        "try:\n"
+        "    if rank == 1:\n"
+        "        time.sleep(1.0)                 # the peer is inside the next collective by now\n"
+        "        raise RuntimeError('rank-local failure mid-solve')\n"
+        "    dist.all_reduce(t)                  # never matched by rank 1\n"
+        "    failed = False\n"
+        "finally:\n"
+        "    g._shutdown_distributed(failed)\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29619", str(runner)]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0
+    assert "rank-local failure mid-solve" in r.stderr
+    assert time.time() - t0 < 120

@@ -201,11 +201,17 @@ def _chain_model(n, widths=(20, 15, 10), seed=0, h=1.0):
     return model, pb, mv, md
 
 
+# engines the oracle comparisons run on: the one the product ships (MFMA32, default) and one cross-check engine
+ORACLE_WG = [3, 1]
+
+
+@pytest.mark.parametrize("wg", ORACLE_WG)
 @pytest.mark.parametrize("fe", [0, 1])
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 4097, 100_000])
-def test_oracle_parity_chain_sizes(n, fe):
-    """HIP vs oracle on the synthetic chain (SURVEY §8d inputs, h = 3/n); sizes straddle wave (64)
-    and block (128/256) edges.  fe=0 is the reference's operation order: fe = ke@u_e cancels in
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 129, 511, 513, 4097, 100_000])
+def test_oracle_parity_chain_sizes(n, fe, wg):
+    """HIP vs oracle on the synthetic chain (SURVEY §8d inputs, h = 3/n); sizes straddle tile (32), wave (64)
+    and block (128/256/512) edges — the MFMA32 engine's tail handling (lanes past the end redo the last element
+    and do not store / count) included.  fe=0 is the reference's operation order: fe = ke@u_e cancels in
     float32 once |ke||u| >> |fe| (long chains), so f_int is compared on the scale |ke||u| that
     sets its round-off and the derived quantities only while that noise is small (n <= 129).
     fe=1 (delta formulation) has no cancellation and is compared tightly at every size."""
@@ -218,7 +224,7 @@ def test_oracle_parity_chain_sizes(n, fe):
     geo = orc.element_geometry(pb)
     mode = "delta" if fe else "reference"
     ref = orc.loss_and_grads(pb, geo, u, lam, 1.0, 100.0, fe_mode=mode)
-    eng = _engine(model, mv, md, 1, fe)
+    eng = _engine(model, mv, md, wg, fe)
     losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), lam, 1.0, 100.0)
     gu, gt = gu.cpu().numpy(), gt.cpu().numpy()
     f_int = eng.internal_force(torch.from_numpy(u), lam).cpu().numpy()
@@ -239,7 +245,8 @@ def test_oracle_parity_chain_sizes(n, fe):
         assert rel_err(gt, ref_t) < 5e-4
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("wg", ORACLE_WG)
+def test_full_size_properties(wg):
     """BASELINE size (10^6 elements, example4 shape): size-independent properties of the HIP path.
     (1) element forces are self-equilibrated, so sum(f_int) = 0 up to round-off;
     (2) f_int is linear in u;
@@ -247,7 +254,7 @@ def test_full_size_properties():
     (4) grad_u = K^T g: <g_f, K v> == <K^T g_f, v> (adjoint identity) for a random v."""
     n = 1_000_000
     model, pb, mv, md = _chain_model(n, h=3.0 / n)
-    eng = _engine(model, mv, md, 1)
+    eng = _engine(model, mv, md, wg)
     x = np.arange(n + 1) * (3.0 / n)
     u = np.zeros(2 * (n + 1), dtype=np.float32)
     u[0::2] = (0.6 * x * (1.0 + 0.05 * np.sin(7.0 * x))).astype(np.float32)
@@ -277,14 +284,16 @@ def test_full_size_properties():
     assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), abs(rhs), 1e-30) + 1e-3 * scale
 
 
-def test_autograd_function_matches_fused_gradients():
+@pytest.mark.parametrize("wg", ORACLE_WG)
+def test_autograd_function_matches_fused_gradients(wg, monkeypatch):
     """The torch.autograd.Function (assemble_system_torch seam) reproduces the fused loss gradients
     when the loss of solver.py:267-283 is written with torch ops on top of it."""
     from pinn_fem_amd.fem.nn_assembly import assemble_system_torch
     rec = load_npz("step_example4_mid.npz")
     parsed = product_example("example4", theta_from(rec))
     model, md = parsed["model"], parsed["measured_data"]
-    eng = _engine(model, md["values"], md["dofs"], 1)
+    monkeypatch.setenv("PINNFEM_WG_MODE", str(wg))        # the engine assemble_system_torch builds for itself
+    eng = _engine(model, md["values"], md["dofs"], wg)
     losses, gu, gt = eng.loss_and_grads(torch.from_numpy(rec["u"]), float(rec["lam"]), 1.0, 100.0)
     gu, gt = gu.clone(), gt.clone()
     dev = eng.device
@@ -535,8 +544,9 @@ def _random_truss(n_nodes, rng, hub_degree=0):
     return nodes, el
 
 
+@pytest.mark.parametrize("wg", [3, 2])
 @pytest.mark.parametrize("n_nodes,hub", [(400, 0), (2500, 300)])
-def test_irregular_truss_vs_oracle(n_nodes, hub):
+def test_irregular_truss_vs_oracle(n_nodes, hub, wg):
     """General connectivity: shuffled element order, random orientation, node degree up to 300."""
     from pinn_fem_amd.fem.model import FEMModel, Material
     from pinn_fem_amd.fem.properties import NNProperty
@@ -558,7 +568,7 @@ def test_irregular_truss_vs_oracle(n_nodes, hub):
                      young=orc.NetParams(th[0:6], 2.0), area=orc.NetParams(th[6:12], 0.3),
                      measured_vals=mv, measured_dofs=md)
     ref = orc.loss_and_grads(pb, orc.element_geometry(pb), u, 0.8, 1.0, 100.0)
-    eng = _engine(model, mv, md, 2)
+    eng = _engine(model, mv, md, wg)
     losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.8, 1.0, 100.0)
     f_int = eng.internal_force(torch.from_numpy(u), 0.8).cpu().numpy()
     assert rel_err(f_int, ref.f_int) < 5e-6
@@ -756,8 +766,9 @@ def test_newton_raphson_errors_like_the_reference():
         solve_nr(mech, SolverConfig(max_iterations=3))
 
 
+@pytest.mark.parametrize("wg", [3, 2])
 @pytest.mark.parametrize("panels", [1, 16, 33, 1000])
-def test_warren_girder_vs_oracle(panels):
+def test_warren_girder_vs_oracle(panels, wg, monkeypatch):
     """The synthetic 2-D truss of bench.py's second mesh (Warren girder, inclined members, node degree 4):
     one loss/gradient evaluation and 12 GD iterations against the oracle."""
     from pinn_fem_amd.fem.solver import SolverConfig, solve_gd
@@ -780,7 +791,8 @@ def test_warren_girder_vs_oracle(panels):
     u[fixed] = 0.0
     geo = orc.element_geometry(pb)
     ref = orc.loss_and_grads(pb, geo, u, 0.6, 1.0, 100.0)
-    eng = _engine(model, mv, md, 2, 0)
+    monkeypatch.setenv("PINNFEM_WG_MODE", str(wg))        # solve_gd below builds its own engine
+    eng = _engine(model, mv, md, wg, 0)
     losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.6, 1.0, 100.0)
     assert abs(losses["loss_total"] - ref.loss_total) < 2e-5 * abs(ref.loss_total)
     assert rel_err(gu.cpu().numpy(), ref.grad_u) < 2e-5
@@ -973,6 +985,166 @@ def test_full_size_loss_and_grads_vs_oracle_prefix():
     k = 2 * (m - 1)
     scale = np.max(np.abs(ref.grad_u[:k]))
     assert np.max(np.abs(gu1[:k] - ref.grad_u[:k])) < 2e-5 * scale
+
+
+def _theta_tensors_like(ref_list, flat):
+    """split the engine's flat gradient into the oracle's tensor list (active tensors only)"""
+    out, o = [], 0
+    for g in ref_list:
+        if g is None:
+            continue
+        out.append(flat[o:o + g.size].reshape(g.shape))
+        o += g.size
+    assert o == flat.size
+    return out
+
+
+def test_full_size_loss_and_grads_vs_oracle_all_elements():
+    """the DEFAULT engine (MFMA32) and the DEFAULT element-force formulation at the bench's state —
+    10^6 elements, example4 shape, five GD iterations from u = 0 at load factor 0.1 — against the oracle over ALL
+    elements: loss terms, grad_u on every dof, and EVERY parameter-gradient tensor.  The oracle accumulates its sums
+    over elements in float64 (acc64; per-element terms stay float32), so the tolerance is the device path's own:
+    fixed-order float32 partial sums over 10^6 terms and 2^-22 products.  Bounds: loss 2e-6, grad_u 1e-5 of its
+    maximum, each grad_theta tensor 2e-5 of that tensor's maximum (measured ~3e-6)."""
+    from bench import build_model
+    from pinn_fem_amd.engine import HipEngine
+    from pinn_fem_amd.fem.solver import SolverConfig
+    n = 1_000_000
+    model, mv, md, _ = build_model(n, "ex4")
+    eng = HipEngine(model, mv, md)
+    assert eng.wg_mode == 3 and eng.fe_mode == 0
+    cfg = SolverConfig(max_iterations=10, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
+    eng.begin(None, 0.1, cfg, want_history=False)
+    eng.iterate(5, use_graph=False)
+    torch.cuda.synchronize()
+    u = eng.u.cpu().numpy().copy()
+    theta = [p.detach().cpu().numpy().copy() for p in model.material.get_all_torch_params()]
+    losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.1, 1.0, 100.0)
+    gu, gt = gu.cpu().numpy().copy(), gt.cpu().numpy().copy()
+    pb = orc.Problem(nodes=model.nodes, elements=model.elements, loads=model.loads, fixed_dofs=model.fixed_dofs,
+                     dimension=2, young=orc.NetParams(theta[0:6]), area=orc.NetParams(theta[6:12]),
+                     density=orc.NetParams(theta[12:18]), measured_vals=mv, measured_dofs=md)
+    ref = orc.loss_and_grads(pb, orc.element_geometry(pb), u, 0.1, 1.0, 100.0, acc64=True)
+    assert abs(losses["loss_total"] - ref.loss_total) < 2e-6 * abs(ref.loss_total)
+    assert abs(losses["loss_physics"] - ref.loss_physics) < 2e-6 * abs(ref.loss_physics)
+    assert abs(losses["loss_data"] - ref.loss_data) < 2e-6 * abs(ref.loss_data)
+    assert np.max(np.abs(gu - ref.grad_u)) < 1e-5 * np.max(np.abs(ref.grad_u))
+    active = [g for g in ref.grad_theta if g is not None]
+    assert len(active) == 12
+    for k, (got, want) in enumerate(zip(_theta_tensors_like(ref.grad_theta, gt), active)):
+        assert np.max(np.abs(got - want)) < 2e-5 * max(np.max(np.abs(want)), 1e-30), k
+
+
+@pytest.mark.parametrize("direction", ["rising", "falling"])
+def test_backward_running_rescale_vs_oracle(direction):
+    """the MFMA32 backward's running power-of-two rescale.  A wave walks its 64-element tasks in
+    ascending order, scales each task's back-propagated gradients by S = 2^14 / (max |g_z| * weight bound), lets S only
+    FALL over its loop and multiplies its accumulated gradient tiles by the (exact) ratio when it does.  Two blocks
+    (n_part_blocks = 2 -> 16 waves, ~20 tasks per wave on 20000 elements) and a displacement field whose strain grows
+    (falls) by 2^20 along the bar, so that |g_z| ~ strain^2 sweeps 2^40: "rising" rescales at nearly every task,
+    "falling" keeps the first S while the later tasks' operands shrink towards the f16 underflow range.  Gradients
+    against the oracle (float64 sums): each tensor within 3e-5 of its maximum."""
+    n = 20_000
+    model, pb, mv, md = _chain_model(n, h=1.0)
+    from pinn_fem_amd.engine import HipEngine
+    eng = HipEngine(model, mv, md, n_part_blocks=2)
+    assert eng.wg_mode == 3
+    e = np.arange(n, dtype=np.float64)
+    expo = -10.0 + 20.0 * e / (n - 1)
+    if direction == "falling":
+        expo = expo[::-1]
+    strain = np.exp2(expo) * (1.0 + 0.3 * np.sin(0.37 * e))
+    u = np.zeros(2 * (n + 1), dtype=np.float32)
+    u[2::2] = np.cumsum(strain).astype(np.float32)
+    losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.6, 1.0, 0.0, )
+    gt = gt.cpu().numpy().copy()
+    ref = orc.loss_and_grads(pb, orc.element_geometry(pb), u, 0.6, 1.0, 0.0, acc64=True)
+    assert np.all(np.isfinite(gt))
+    active = [g for g in ref.grad_theta if g is not None]
+    for k, (got, want) in enumerate(zip(_theta_tensors_like(ref.grad_theta, gt), active)):
+        assert np.max(np.abs(got - want)) < 3e-5 * max(np.max(np.abs(want)), 1e-30), (direction, k)
+    assert abs(losses["loss_total"] - ref.loss_total) < 2e-5 * abs(ref.loss_total)
+
+
+@pytest.mark.parametrize("lam", [1.0e3, 3.0e4])
+def test_large_load_factor_gradients_vs_oracle(lam):
+    """the load factor is an INPUT of the nets and so an operand of the layer-1 gradient tile, where
+    it travels as split f16; it carries its own power-of-two scale (host-derived, like the coordinates') — with the fixed
+    factor 256 of round 2 it overflowed f16 from |lam| >= 256 and dW1[:,0] came out wrong without any sign.  Small
+    layer-1 weights keep tanh off saturation so that the gradient is not round-off."""
+    rec = load_npz("step_chain300_ex4shape.npz")
+    theta = theta_from(rec)
+    for k in (0, 6):
+        theta[k] = theta[k].copy()
+        theta[k][:, 0] *= np.float32(1.0 / lam)         # weights of the load-factor column
+    model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, 10), (1.0, 1.0, 1.0), theta)
+    pb = mesh_problem(dict(rec, **{f"theta_{i}": t for i, t in enumerate(theta)}), (20, 15, 10), (1.0, 1.0, 1.0))
+    ref = orc.loss_and_grads(pb, orc.element_geometry(pb), rec["u"], lam, 1.0, 100.0, acc64=True)
+    for wg in (3, 2):
+        eng = _engine(model, rec["meas_vals"], rec["meas_dofs"], wg)
+        losses, gu, gt = eng.loss_and_grads(torch.from_numpy(rec["u"]), lam, 1.0, 100.0)
+        gt = gt.cpu().numpy()
+        active = [g for g in ref.grad_theta if g is not None]
+        for k, (got, want) in enumerate(zip(_theta_tensors_like(ref.grad_theta, gt), active)):
+            assert np.max(np.abs(got - want)) < 1e-3 * max(np.max(np.abs(want)), 1e-30), (wg, k)
+        # every column of W1 on its own scale (the load-factor column's gradient is lam times the bias gradient)
+        for k in (0, 6):
+            for c in range(3):
+                got = _theta_tensors_like(ref.grad_theta, gt)[k][:, c]
+                want = active[k][:, c]
+                assert np.max(np.abs(got - want)) < 1e-3 * np.max(np.abs(want)), (wg, k, c)
+
+
+def test_beyond_infinity_cache_1e7_elements():
+    """10^7 elements (working set ~1.2 GB, far beyond the 256 MiB Infinity Cache), example4 shape,
+    default engine and formulation: (1) sum f_int = 0 (self-equilibrated element forces); (2) ten iterations replayed as
+    the hipGraph == the same ten launched eagerly, bit for bit; (3) loss terms / grad_u on the first 5000 elements'
+    interior dofs against the oracle on that prefix (delta formulation on both sides: |u| reaches 10^4 on this bar)."""
+    from bench import build_model
+    from pinn_fem_amd.engine import HipEngine
+    from pinn_fem_amd.fem.solver import SolverConfig
+    n, m = 10_000_000, 5000
+    model, mv, md, _ = build_model(n, "ex4")
+    theta0 = [p.detach().cpu().numpy().copy() for p in model.material.get_all_torch_params()]
+    cfg = SolverConfig(max_iterations=12, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
+    eng = HipEngine(model, mv, md)
+    outs = []
+    for use_graph in (True, False):
+        with torch.no_grad():
+            for p, a in zip(model.material.get_all_torch_params(), theta0):
+                p.copy_(torch.from_numpy(a).to(p.device))
+        eng.begin(None, 0.1, cfg, want_history=True)
+        eng.iterate(10, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert eng.state().iter == 10
+        outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.history(10).copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][2], outs[1][2]) and np.all(np.isfinite(outs[0][2]))
+    # (1) equilibrium of the element forces at a smooth displacement field
+    x = np.arange(n + 1, dtype=np.float64)
+    u = np.zeros(2 * (n + 1), dtype=np.float32)
+    u[0::2] = (1e-3 * x * (1.0 + 0.05 * np.sin(x / 50.0))).astype(np.float32)
+    ut = torch.from_numpy(u)
+    f = eng.internal_force(ut, 0.6).double()
+    scale = float(eng.prop_e[:n].abs().max() * eng.prop_a[:n].abs().max() * np.abs(u).max())
+    assert abs(float(f.sum())) < 1e-6 * scale * np.sqrt(n)
+    del f
+    # (3) prefix oracle, delta formulation
+    eng2 = HipEngine(model, mv, md, fe_mode=1)
+    losses, gu, gt = eng2.loss_and_grads(ut, 0.6, 1.0, 100.0)
+    gu = gu[: 2 * (m + 1)].cpu().numpy().copy()
+    assert np.all(np.isfinite(gt.cpu().numpy()))
+    theta = [p.detach().cpu().numpy().copy() for p in model.material.get_all_torch_params()]
+    mask = np.asarray(md) < 2 * (m + 1)
+    sub_md = np.asarray(md)[mask]
+    sub = orc.Problem(nodes=model.nodes[: m + 1], elements=model.elements[:m], loads=model.loads[: 2 * (m + 1)],
+                      fixed_dofs=model.fixed_dofs[model.fixed_dofs < 2 * (m + 1)], dimension=2,
+                      young=orc.NetParams(theta[0:6]), area=orc.NetParams(theta[6:12]), density=1.0,
+                      measured_vals=np.asarray(mv)[mask], measured_dofs=sub_md)
+    ref = orc.loss_and_grads(sub, orc.element_geometry(sub), u[: 2 * (m + 1)], 0.6, 1.0, 100.0 * sub_md.size / len(md),
+                             fe_mode="delta")
+    k = 2 * (m - 1)
+    assert np.max(np.abs(gu[:k] - ref.grad_u[:k])) < 2e-5 * np.max(np.abs(ref.grad_u[:k]))
 
 
 def test_config1_ex3_shape_1e5_vs_oracle():
