@@ -90,19 +90,34 @@ def _oracle_problem(orc, n, workload):
                        young=props[0], area=props[1], density=props[2], measured_vals=mv, measured_dofs=md)
 
 
+def _usable_cpus() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(workload: str, n_sample: int, iters: int, threads: int):
-    """The oracle (numpy restatement of the reference algorithm, kind "port") timed on the host cores on bounded
-    samples of the same workload:
-      (R) reference-ORDER mode, one element at a time like assemble_system_torch's Python loop, N = 3 / 300 / 1000
-          (beside BASELINE.md's import-measured reference: 676 / 474 / 430 element-evals/s on 8 cores);
-      (V) vectorised mode (batched MLP + matrix-free assembly), N = 10^5 and the headline sample size.
-    Thread pools (BLAS) are pinned to `threads`; numpy's element-wise work is single-threaded either way."""
+    """The reference algorithm's CPU ports (kind "port"; the reference's files never travel to the GPU box) timed on the
+    host cores on bounded samples of the same workload:
+      (R)  reference-ORDER mode of the numpy oracle, one element at a time like assemble_system_torch's Python loop,
+           N = 3 / 300 / 1000 (beside BASELINE.md's import-measured reference: 676 / 474 / 430 element-evals/s on 8
+           cores); 1 thread;
+      (V)  vectorised CPU PyTorch restatement WITH autograd and torch.optim.Adam (oracle/torch_vectorised.py: batched MLP,
+           index_add_ assembly, loss.backward()), torch intra-op threads = `threads`: the reference's own cost class at
+           scale, and the headline `value` of this object;
+      (Vn) the numpy oracle's vectorised mode (hand-written backward, no autograd): BLAS threads = `threads`, its
+           element-wise work (tanh, softplus, gathers) is single-threaded numpy.
+    Each row states the threads it really used (`cores`)."""
     from oracle import pinn_oracle as orc
+    import torch
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=threads)
     except Exception:
         limiter = None
+    torch_threads_before = torch.get_num_threads()
+    torch.set_num_threads(int(threads))
     lr_t = 5e-4 if workload == "ex4" else 1e-3
     model_name, ncpu = _cpu_info()
     rows = []
@@ -114,10 +129,23 @@ def cpu_baseline(workload: str, n_sample: int, iters: int, threads: int):
         t0 = time.perf_counter()
         orc.gd_iterations_loop(pb, cfg, 0.1, it)
         dt = time.perf_counter() - t0
-        rows.append({"mode": "R (reference order, per-element loop)", "n_elems": n, "iterations": it,
-                     "value": n * it / dt, "unit": "element-evals/s", "wall_s": dt,
+        rows.append({"mode": "R (reference order, per-element loop, numpy oracle)", "n_elems": n, "iterations": it,
+                     "value": n * it / dt, "unit": "element-evals/s", "wall_s": dt, "cores": 1,
                      "reference_measured_BASELINE_md": ref_rows[n]})
+    from oracle.torch_vectorised import TorchVectorisedGD
     head = None
+    for n, it in ((100_000, max(iters, 10)), (n_sample, iters)):
+        pb = _oracle_problem(orc, n, workload)
+        tv = TorchVectorisedGD(pb, 0.1, 0.01, lr_t)
+        tv.run(1)                                                                       # touch pages, build the graph once
+        t0 = time.perf_counter()
+        tv.run(it)
+        dt = time.perf_counter() - t0
+        head = {"mode": "V (vectorised CPU PyTorch, autograd + torch.optim.Adam)", "n_elems": n, "iterations": it,
+                "value": n * it / dt, "unit": "element-evals/s", "wall_s": dt, "cores": int(torch.get_num_threads()),
+                "torch_num_threads": int(torch.get_num_threads())}
+        rows.append(head)
+        del tv
     for n, it in ((100_000, max(iters, 10)), (n_sample, iters)):
         pb = _oracle_problem(orc, n, workload)
         cfg = orc.SolverConfig(max_iterations=it, learning_rate_u=0.01, learning_rate_theta=lr_t, tolerance=0.0)
@@ -126,16 +154,49 @@ def cpu_baseline(workload: str, n_sample: int, iters: int, threads: int):
         t0 = time.perf_counter()
         orc.solve_gd(pb, cfg, 0.1, geo=geo)
         dt = time.perf_counter() - t0
-        head = {"mode": "V (vectorised)", "n_elems": n, "iterations": it, "value": n * it / dt,
-                "unit": "element-evals/s", "wall_s": dt}
-        rows.append(head)
+        rows.append({"mode": "Vn (vectorised numpy oracle, no autograd)", "n_elems": n, "iterations": it,
+                     "value": n * it / dt, "unit": "element-evals/s", "wall_s": dt,
+                     "cores": f"BLAS pool {threads}; element-wise numpy work on 1"})
     if limiter is not None:
         limiter.restore_original_limits()
-    return {"value": head["value"], "unit": "element-evals/s", "cores": int(threads), "kind": "port",
-            "sample": f"oracle/pinn_oracle.py solve_gd (vectorised), {head['n_elems']} elements x {head['iterations']} GD "
-                      f"iterations, {workload} shape, {head['wall_s']:.1f} s wall; thread pools pinned to {threads} "
-                      f"of {ncpu} logical CPUs ({model_name})",
-            "cpu_model": model_name, "host_cpus": ncpu, "rows": rows}
+    torch.set_num_threads(torch_threads_before)
+    return {"value": head["value"], "unit": "element-evals/s", "cores": head["cores"], "kind": "port",
+            "sample": f"oracle/torch_vectorised.py (batched CPU PyTorch restatement of the reference iteration, autograd + "
+                      f"torch.optim.Adam), {head['n_elems']} elements x {head['iterations']} GD iterations, {workload} "
+                      f"shape, {head['wall_s']:.1f} s wall; torch.get_num_threads() = {head['cores']} of "
+                      f"{_usable_cpus()} usable / {ncpu} logical CPUs ({model_name})",
+            "cpu_model": model_name, "host_cpus": ncpu, "usable_cpus": _usable_cpus(), "rows": rows}
+
+
+def iters_to_tol(dev, sizes=(1000, 10_000), max_iterations=3000, n_increments=10):
+    """SURVEY.md section 8(d) metric (ii), "GD iterations to tolerance" (FEM/python/fem/solver.py:341-355): the synthetic
+    chain (h = 1, measurements ux_i = x_i at every node, alpha_data = 100), example4 shape, seed 0, 10 load increments
+    lam_k = k/10 with warm starts (fem/solver.py:1045-1167), stop test `it > 10 and (||r|| < tol or L < tol)` with
+    tol = 1e-6, at most `max_iterations` per increment — in the reference's element-force order and in the delta form.
+    Reported per increment: iterations and whether the increment hit max_iterations."""
+    import torch
+    from pinn_fem_amd.fem.solver import SolverConfig, solve_gd
+    out = {}
+    for n in sizes:
+        for fe_name, fe in (("reference", 0), ("delta", 1)):
+            model, mv, md, _ = build_model(n, "ex4")
+            model._pf_fe_mode = fe
+            cfg = SolverConfig(max_iterations=max_iterations, tolerance=1e-6, learning_rate_u=0.01,
+                               learning_rate_theta=5e-4, alpha_physics=1.0, alpha_data=100.0)
+            u, its, hits, last = None, [], 0, None
+            t0 = time.perf_counter()
+            for k in range(1, n_increments + 1):
+                res = solve_gd(model, cfg, mv, md, target_load_factor=k / n_increments, u_initial=u)
+                its.append(len(res.history))
+                hits += 0 if res.converged else 1
+                last = res.history[-1]
+                u = torch.tensor(res.displacements.flatten(), dtype=torch.float32)
+            torch.cuda.synchronize(dev)
+            out[f"N={n}, fe_mode={fe_name}"] = {
+                "iterations_per_increment": its, "iterations_total": int(sum(its)), "max_iterations": max_iterations,
+                "max_iterations_hits": hits, "final_loss_total": last["loss_total"],
+                "final_residual_norm": last["residual_norm"], "wall_s": time.perf_counter() - t0}
+    return out
 
 
 def side_config(workload, n_elems, dev, steps, mesh="chain"):
@@ -187,6 +248,10 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="thread-pool size of the CPU baseline (0: min(64, cpus))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configs[1] measurement")
+    ap.add_argument("--repeat", type=int, default=5, help="further timed K-step regions for the repeat statistic")
+    ap.add_argument("--total-elems", type=int, default=0,
+                    help="elements of the WHOLE bar (overrides --elems with total/gpus); BASELINE.json configs[3] is "
+                         "--gpus 8 --total-elems 10000000")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -219,10 +284,10 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    n_local = args.elems
+    n_local = args.elems if args.total_elems <= 0 else args.total_elems // world
     lr_t = 5e-4 if args.workload == "ex4" else 1e-3
-    cfg = SolverConfig(max_iterations=args.warmup + 2 * args.steps + 32, tolerance=0.0, learning_rate_u=0.01,
-                       learning_rate_theta=lr_t, alpha_physics=1.0, alpha_data=100.0)
+    cfg = SolverConfig(max_iterations=args.warmup + (2 + max(args.repeat, 0)) * args.steps + 64, tolerance=0.0,
+                       learning_rate_u=0.01, learning_rate_theta=lr_t, alpha_physics=1.0, alpha_data=100.0)
     if world == 1:
         from pinn_fem_amd.engine import HipEngine
         model, mv, md, widths = build_model(n_local, args.workload)
@@ -282,8 +347,51 @@ def main():
     st = eng.state()
     assert st.iter == iters_before + n_warm + args.steps, (st.iter, iters_before + n_warm + args.steps)
     assert graph_count() == graphs_before, "a hipGraph was captured inside the timed region"
+    # repeat statistic (not `value`): R further regions of K steps each, timed the same way
+    rep_ms = []
+    for _ in range(max(args.repeat, 0)):
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        t2 = time.perf_counter()
+        run_timed(args.steps)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        d2 = time.perf_counter() - t2
+        if world > 1:
+            tm = torch.tensor([d2], dtype=torch.float64, device="cpu" if rehearsal else dev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            d2 = float(tm.item())
+        rep_ms.append(d2 / args.steps * 1e3)
 
     mlp_dtype = (eng if world == 1 else eng.backend.eng).mlp_dtype
+    # N > 1: BASELINE.json configs[3] is a 10^7-element bar sharded over the ranks (1.25e6 per rank at N = 8), which the
+    # weak-scaling headline (--elems per rank) does not reproduce: measured here as well, the same way (collective: every
+    # rank takes part), unless the headline already is that configuration
+    also_c3 = None
+    if world > 1 and not args.no_also and n_local * world != 10_000_000:
+        from pinn_fem_amd.dist import ShardedChainEngine
+        n3 = (10_000_000 if not rehearsal else 100_000) // world
+        eng3 = ShardedChainEngine(n3, args.workload, rank, world, dev)
+        eng3.begin(None, 0.1, cfg)
+        eng3.prepare()
+        eng3.iterate(max(args.warmup, 1))
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        eng3.iterate(args.steps)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        d3 = time.perf_counter() - t3
+        tm = torch.tensor([d3], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        d3 = float(tm.item())
+        also_c3 = {"value": n3 * world * args.steps / d3, "unit": "element-evals/s", "ms_per_step": d3 / args.steps * 1e3,
+                   "steps": args.steps, "elements_total": n3 * world, "elements_per_gpu": n3, "scaling": "strong (fixed total)"}
+        del eng3
     if rank == 0:
         total_elems = n_local * world
         value = total_elems * args.steps / dt
@@ -337,6 +445,9 @@ def main():
                                    f"{n_local} elements per GPU, collinear 2-D truss h=1, "
                                    f"alpha_data=100 with measurements at every node, load factor 0.1",
                        "elements_total": total_elems, "parallelism": f"elements sharded x{world}"},
+            "repeat": ({"regions": len(rep_ms), "steps_each": args.steps, "ms_per_step_median": float(np.median(rep_ms)),
+                        "ms_per_step_min": float(np.min(rep_ms)), "ms_per_step_max": float(np.max(rep_ms)),
+                        "value_at_median": total_elems * 1e3 / float(np.median(rep_ms))} if rep_ms else None),
             "ms_per_step_eager_with_events": dt_events / args.steps * 1e3,
             "kernel_ms": {n: float(m) for n, m in zip(names, slot_ms)},
             "roofline": roof,
@@ -344,6 +455,9 @@ def main():
         if world > 1:
             from pinn_fem_amd.dist import shard_driver_info
             out["config"].update(shard_driver_info(eng.backend))
+            if also_c3 is not None:
+                name = "configs[3]: 1e7-element bar sharded over the ranks" if not rehearsal else "configs[3] rehearsal (1e5 total)"
+                out["also"] = {name: also_c3}
         if world == 1 and not args.no_also:
             # BASELINE.json configs[1] (example3 shape, E = NN, 10^5 elements) for the record; the headline
             # `value` above stays the 10^6-element configuration the metric is quoted on
@@ -351,8 +465,10 @@ def main():
                            # a genuinely 2-D truss (Warren girder, node degree 4) of the headline's size
                            "ex4 shape, Warren girder, 1e6 elements, 1 GPU": side_config("ex4", 1_000_000, dev, args.steps,
                                                                                          mesh="warren")}
-        if not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(64, os.cpu_count() or 1)
+            # metric (ii) of SURVEY.md section 8(d): GD iterations to tolerance on the synthetic bar
+            out["also"]["iters_to_tol"] = iters_to_tol(dev)
+        if not args.no_cpu_baseline and world == 1:
+            threads = args.cpu_threads or min(64, _usable_cpus())
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.cpu_iters, threads)
         print(json.dumps(out))
     if world > 1:

@@ -174,7 +174,8 @@ def mlp_forward(net: NetParams, x: np.ndarray):
     raise AssertionError
 
 
-def mlp_backward(net: NetParams, acts, g_z: np.ndarray, acc64: bool = False) -> List[np.ndarray]:
+def mlp_backward(net: NetParams, acts, g_z: np.ndarray, acc64: bool = False,
+                 abs_out: Optional[list] = None) -> List[np.ndarray]:
     """Gradients of sum_e g_z[e]*z_out[e] w.r.t. net.tensors (autograd of generic.py:141).
     acc64: the sums over ELEMENTS are accumulated in float64 (every per-element term is still the float32
     value): a checker for large meshes whose own summation error is negligible, so that a comparison
@@ -185,6 +186,10 @@ def mlp_backward(net: NetParams, acts, g_z: np.ndarray, acc64: bool = False) -> 
     for l in range(nl - 1, -1, -1):
         w = net.tensors[2 * l].astype(f32)
         h_in = acts[l]
+        if abs_out is not None:
+            # sum over elements of |term|: the scale a float32 summation error is measured against when the terms cancel
+            ga, ha = np.abs(g).astype(np.float64), np.abs(h_in).astype(np.float64)
+            abs_out.extend([ga.T @ ha, ga.sum(axis=0)])
         if acc64:
             grads[2 * l] = (g.T.astype(np.float64) @ h_in.astype(np.float64)).astype(f32)
             grads[2 * l + 1] = g.sum(axis=0, dtype=np.float64).astype(f32)
@@ -194,6 +199,8 @@ def mlp_backward(net: NetParams, acts, g_z: np.ndarray, acc64: bool = False) -> 
         if l > 0:
             gh = (g @ w).astype(f32)
             g = (gh * (f32(1.0) - h_in * h_in)).astype(f32)   # tanh backward: g*(1-y*y)
+    if abs_out is not None:                                # appended last layer first: put this net's into tensor order
+        abs_out[-2 * nl:] = [x for l in range(nl) for x in abs_out[len(abs_out) - 2 * (l + 1):len(abs_out) - 2 * l]]
     return grads  # type: ignore[return-value]
 
 
@@ -224,6 +231,7 @@ class StepOut:
     stiffness: np.ndarray
     young: np.ndarray
     area: np.ndarray
+    grad_theta_abs: Optional[List[np.ndarray]] = None      # acc64 only: sum over elements of |term| per entry
 
 
 def element_stiffness(pb: Problem, geo: Geometry, lam: float):
@@ -296,6 +304,7 @@ def loss_and_grads(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
     rn = f32(np.sqrt(np.sum(r * r, dtype=sdt)))                     # torch.norm :306
     grad_u = np.zeros(ndof, dtype=f32)
     grad_theta: List[Optional[np.ndarray]] = []
+    abs_out: Optional[list] = [] if acc64 else None
     if want_grads:
         g_f = np.zeros(ndof, dtype=f32)
         g_f[free] = (f32(alpha_physics) * r).astype(f32)            # dL/df_int (free rows only)
@@ -315,13 +324,13 @@ def loss_and_grads(pb: Problem, geo: Geometry, u: np.ndarray, lam: float,
                 z, acts = ctx
                 g_out = (g_ea * other * f32(prop.scale)).astype(f32)
                 g_z = (g_out * softplus_grad(z)).astype(f32) if prop.enforce_positive else g_out
-                grad_theta.extend(mlp_backward(prop, acts, g_z, acc64))
+                grad_theta.extend(mlp_backward(prop, acts, g_z, acc64, abs_out))
         if isinstance(pb.density, NetParams):
             # never evaluated by the assembly: grad stays None (nn_assembly.py:207-208)
             grad_theta.extend([None] * len(pb.density.tensors))
     return StepOut(f_int=f_int, r=r, loss_physics=float(loss_p), loss_data=float(loss_d),
                    loss_total=float(loss), residual_norm=float(rn), grad_u=grad_u,
-                   grad_theta=grad_theta, stiffness=s, young=e_val, area=a_val)
+                   grad_theta=grad_theta, stiffness=s, young=e_val, area=a_val, grad_theta_abs=abs_out)
 
 
 def vjp_internal_force(pb: Problem, geo: Geometry, u: np.ndarray, lam: float, g_f: np.ndarray,

@@ -1043,7 +1043,9 @@ def test_backward_running_rescale_vs_oracle(direction):
     (n_part_blocks = 2 -> 16 waves, ~20 tasks per wave on 20000 elements) and a displacement field whose strain grows
     (falls) by 2^20 along the bar, so that |g_z| ~ strain^2 sweeps 2^40: "rising" rescales at nearly every task,
     "falling" keeps the first S while the later tasks' operands shrink towards the f16 underflow range.  Gradients
-    against the oracle (float64 sums): each tensor within 3e-5 of its maximum."""
+    against the oracle (float64 sums).  The per-element terms alternate in sign here (g_z follows the residual, a
+    difference of neighbouring element forces), so the sums cancel by orders of magnitude: the error is measured
+    against sum_e |term_e| per entry, the scale of a float32 accumulation — bound 1e-5 (measured ~1e-6)."""
     n = 20_000
     model, pb, mv, md = _chain_model(n, h=1.0)
     from pinn_fem_amd.engine import HipEngine
@@ -1061,8 +1063,14 @@ def test_backward_running_rescale_vs_oracle(direction):
     ref = orc.loss_and_grads(pb, orc.element_geometry(pb), u, 0.6, 1.0, 0.0, acc64=True)
     assert np.all(np.isfinite(gt))
     active = [g for g in ref.grad_theta if g is not None]
-    for k, (got, want) in enumerate(zip(_theta_tensors_like(ref.grad_theta, gt), active)):
-        assert np.max(np.abs(got - want)) < 3e-5 * max(np.max(np.abs(want)), 1e-30), (direction, k)
+    worst = 0.0
+    for k, (got, want, asum) in enumerate(zip(_theta_tensors_like(ref.grad_theta, gt), active, ref.grad_theta_abs)):
+        asum = asum.reshape(want.shape)
+        ratio = float(np.max(np.abs(got - want) / np.maximum(asum, 1e-300)))
+        worst = max(worst, ratio)
+        assert ratio < 1e-5, (direction, k, ratio)
+        assert np.max(np.abs(got - want)) < 1e-5 * np.max(asum), (direction, k)
+    print(f"running rescale [{direction}]: worst |err| / sum|terms| = {worst:.2e}")
     assert abs(losses["loss_total"] - ref.loss_total) < 2e-5 * abs(ref.loss_total)
 
 
@@ -1226,15 +1234,33 @@ def test_bench_contract_single_gpu():
     assert abs(d["value"] - 50000 * 20 / (d["ms_per_step"] * 20e-3)) < 1e-6 * d["value"]
     rf, cb = d["roofline"], d["cpu_baseline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["rows"]) >= 4
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["rows"]) >= 7
+    assert any(r["mode"].startswith("V (vectorised CPU PyTorch") and r["torch_num_threads"] == cb["cores"] for r in cb["rows"])
+    assert d["repeat"]["regions"] == 5 and d["repeat"]["steps_each"] == 20
+
+
+def test_bench_iters_to_tol_entry():
+    """bench.py's metric (ii) helper (GD iterations to tolerance) on a 200-element bar: ten increments, per
+    increment iteration counts within the cap, hits counted, both element-force formulations."""
+    import bench
+    out = bench.iters_to_tol(torch.device("cuda", 0), sizes=(200,), max_iterations=400)
+    assert set(out) == {"N=200, fe_mode=reference", "N=200, fe_mode=delta"}
+    for v in out.values():
+        assert len(v["iterations_per_increment"]) == 10 and all(12 <= k <= 400 for k in v["iterations_per_increment"])
+        assert v["max_iterations_hits"] == sum(1 for k in v["iterations_per_increment"] if k == 400) or v["max_iterations_hits"] <= 10
+        assert np.isfinite(v["final_loss_total"])
 
 
 def test_bench_two_rank_rehearsal():
     """`bench.py --gpus 2` without a launcher starts its own two ranks; here both on this one GPU over gloo
     (PINNFEM_BENCH_ONE_GPU=1: a rehearsal of the N>1 code path, not a multi-GPU number): the sharded driver runs, the
     line reports the whole job (2 x elems per step) and which shard driver ran."""
-    d = _bench_line(["--gpus", "2", "--steps", "10", "--warmup", "2", "--elems", "30000", "--no-cpu-baseline", "--no-also"],
+    d = _bench_line(["--gpus", "2", "--steps", "10", "--warmup", "2", "--elems", "30000", "--no-cpu-baseline", "--repeat", "2"],
                     {"PINNFEM_BENCH_ONE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "REHEARSAL" in d["data"]
+    # the fixed-total configuration beside the weak-scaling headline (configs[3]; 1e5 elements in the rehearsal)
+    (c3,) = d["also"].values()
+    assert c3["elements_total"] == 100_000 and c3["elements_per_gpu"] == 50_000 and c3["value"] > 0
+    assert d["repeat"]["regions"] == 2 and d["repeat"]["ms_per_step_min"] <= d["repeat"]["ms_per_step_median"]
     assert d["config"]["elements_total"] == 60000 and "shard_driver" in d["config"]
     assert abs(d["value"] - 60000 * 10 / (d["ms_per_step"] * 10e-3)) < 1e-6 * d["value"]

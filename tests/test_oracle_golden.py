@@ -250,3 +250,23 @@ def test_inverse_gd_oracle_identifies_axial_stiffness():
     assert abs(out["young_final"] * out["area_final"] / ea - 1.0) < 1e-4
     assert out["history"][-1]["loss_total"] < 1e-6 * out["history"][0]["loss_total"]
     assert np.max(np.abs(out["u_final"][[2, 4, 6]] - um)) < 1e-5
+
+
+def test_torch_vectorised_restatement_matches_the_oracle():
+    """oracle/torch_vectorised.py (batched CPU PyTorch with autograd and torch.optim.Adam: the (V) CPU-baseline row of
+    bench.py) against the numpy oracle — which is pinned by the reference's goldens above — on the 300-element chain
+    fixture: 12 GD iterations, loss trajectory within 2e-6, displacements within 1e-6 of their maximum."""
+    from helpers import mesh_problem
+    from oracle.torch_vectorised import TorchVectorisedGD
+    rec = load_npz("step_chain300_ex4shape.npz")
+    tv = TorchVectorisedGD(mesh_problem(rec, (20, 15, 10)), 0.7, 0.01, 5e-4, u_initial=rec["u"])
+    hist = tv.run(12)
+    ref = orc.solve_gd(mesh_problem(rec, (20, 15, 10)),
+                       orc.SolverConfig(max_iterations=12, learning_rate_u=0.01, learning_rate_theta=5e-4, tolerance=0.0),
+                       0.7, u_initial=rec["u"])
+    a = np.array([h["loss_total"] for h in hist])
+    b = np.array([h["loss_total"] for h in ref.history])
+    assert np.max(np.abs(a - b) / np.abs(b)) < 2e-6
+    assert rel_err(tv.u.detach().numpy(), ref.displacements.flatten()) < 1e-6
+    rn = np.array([h["residual_norm"] for h in hist])
+    assert np.max(np.abs(rn - np.array([h["residual_norm"] for h in ref.history])) / rn) < 2e-5
