@@ -1045,11 +1045,15 @@ def test_backward_running_rescale_vs_oracle(direction):
     "falling" keeps the first S while the later tasks' operands shrink towards the f16 underflow range.  Gradients
     against the oracle (float64 sums).  The per-element terms alternate in sign here (g_z follows the residual, a
     difference of neighbouring element forces), so the sums cancel by orders of magnitude: the error is measured
-    against sum_e |term_e| per entry, the scale of a float32 accumulation — bound 1e-5 (measured ~1e-6)."""
+    against sum_e |term_e| per entry, the scale of a float32 accumulation — bound 2e-5 (float32 noise of the terms
+    themselves: 1e-6 ... 9e-6 on every engine, the exact-f32 one included)."""
     n = 20_000
     model, pb, mv, md = _chain_model(n, h=1.0)
     from pinn_fem_amd.engine import HipEngine
-    eng = HipEngine(model, mv, md, n_part_blocks=2)
+    # element forces in the difference form on both sides: |u| reaches 10^7 at the stiff end of this bar, and the
+    # reference's 4-term dot would bury g_z in cancellation noise that both engines and the oracle share
+    # (tools/rescale_diag.py: 5e-4 of sum|terms| on the exact-f32 engine as well)
+    eng = HipEngine(model, mv, md, n_part_blocks=2, fe_mode=1)
     assert eng.wg_mode == 3
     e = np.arange(n, dtype=np.float64)
     expo = -10.0 + 20.0 * e / (n - 1)
@@ -1058,9 +1062,9 @@ def test_backward_running_rescale_vs_oracle(direction):
     strain = np.exp2(expo) * (1.0 + 0.3 * np.sin(0.37 * e))
     u = np.zeros(2 * (n + 1), dtype=np.float32)
     u[2::2] = np.cumsum(strain).astype(np.float32)
-    losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.6, 1.0, 0.0, )
+    losses, gu, gt = eng.loss_and_grads(torch.from_numpy(u), 0.6, 1.0, 0.0)
     gt = gt.cpu().numpy().copy()
-    ref = orc.loss_and_grads(pb, orc.element_geometry(pb), u, 0.6, 1.0, 0.0, acc64=True)
+    ref = orc.loss_and_grads(pb, orc.element_geometry(pb), u, 0.6, 1.0, 0.0, acc64=True, fe_mode="delta")
     assert np.all(np.isfinite(gt))
     active = [g for g in ref.grad_theta if g is not None]
     worst = 0.0
@@ -1068,7 +1072,7 @@ def test_backward_running_rescale_vs_oracle(direction):
         asum = asum.reshape(want.shape)
         ratio = float(np.max(np.abs(got - want) / np.maximum(asum, 1e-300)))
         worst = max(worst, ratio)
-        assert ratio < 1e-5, (direction, k, ratio)
+        assert ratio < 2e-5, (direction, k, ratio)
         assert np.max(np.abs(got - want)) < 1e-5 * np.max(asum), (direction, k)
     print(f"running rescale [{direction}]: worst |err| / sum|terms| = {worst:.2e}")
     assert abs(losses["loss_total"] - ref.loss_total) < 2e-5 * abs(ref.loss_total)
