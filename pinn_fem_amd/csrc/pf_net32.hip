@@ -60,12 +60,6 @@ namespace {
 
 constexpr bool BF = PF_PREC == 1;
 
-constexpr int NR = PF_NR;                 // accumulator registers per lane that carry real units
-constexpr int KS = NR > 8 ? 2 : 1;        // k-steps of 16 units
-constexpr int NPK = 4 * KS;               // packed f16 pairs per operand set (pairs >= (NR+1)/2 are zero)
-constexpr int NPR = (NR + 1) / 2;         // pairs that carry data
-static_assert(NR >= 1 && NR <= 15, "PF_NR out of range");
-
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
   if constexpr (I < N) {
@@ -149,96 +143,6 @@ __device__ __forceinline__ float wave_max(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 63));
 }
 
-// ---- activations of one tile kept for the backward pass -------------------------------------------------
-template <int L, bool BWD>
-struct TileAct {
-  unsigned hi[L][NPK], lo[L][NPK];   // a'_l = KA tanh(z_l) as packed f16 pairs (pair q = registers 2q, 2q+1)
-  float t[BWD ? L : 1][NR];          // r (1 - r) with tanh = 1 - 2 r: (1 - tanh^2) / 4
-  float aL[NR];                      // a'_L in float (output unit and its gradient)
-};
-
-// Scheduling fence.  Left alone, hipcc serialises each unit's exp -> add -> rcp -> fma chain (the transcendental
-// results are needed a few cycles after issue, so the wave stalls on every step); the stages below issue one kind
-// of instruction for all units of both tiles back to back, which hides those latencies inside the wave.
-#define PF_STAGE() __builtin_amdgcn_sched_barrier(0)
-
-// tanh of the NR pre-activations z[r] * cz of BOTH tiles; writes the packed pairs (and t, aL) of layer LL
-template <int L, bool BWD, int LL>
-__device__ __forceinline__ void activate2(TileAct<L, BWD>& A0, TileAct<L, BWD>& A1, const float (&z0)[NR],
-                                          const float (&z1)[NR], float cz, int dbg = 0) {
-  float e0[NR], e1[NR];
-  PF_STAGE();
-  if (dbg & 4) {   // timing experiment: no transcendentals
-    sfor<0, NR>([&](auto r) { constexpr int R = r; e0[R] = z0[R] * cz; e1[R] = z1[R] * cz; });
-  } else {
-  sfor<0, NR>([&](auto r) {
-    constexpr int R = r;
-    e0[R] = __builtin_amdgcn_exp2f(z0[R] * cz);
-    e1[R] = __builtin_amdgcn_exp2f(z1[R] * cz);
-  });
-  PF_STAGE();
-  sfor<0, NR>([&](auto r) {
-    constexpr int R = r;
-    e0[R] = __builtin_amdgcn_rcpf(e0[R] + 1.0f);
-    e1[R] = __builtin_amdgcn_rcpf(e1[R] + 1.0f);
-  });
-  }
-  PF_STAGE();
-  float a0[2 * NPR], a1[2 * NPR];
-  sfor<0, NR>([&](auto r) {
-    constexpr int R = r;
-    a0[R] = fmaf(-2.0f * PF_N32_KA, e0[R], PF_N32_KA);
-    a1[R] = fmaf(-2.0f * PF_N32_KA, e1[R], PF_N32_KA);
-    if constexpr (BWD) {
-      A0.t[LL - 1][R] = fmaf(-e0[R], e0[R], e0[R]);
-      A1.t[LL - 1][R] = fmaf(-e1[R], e1[R], e1[R]);
-    }
-    if constexpr (LL == L) { A0.aL[R] = a0[R]; A1.aL[R] = a1[R]; }
-  });
-  if constexpr (NR & 1) { a0[NR] = 0.f; a1[NR] = 0.f; }
-  sfor<0, NPK>([&](auto q) {
-    constexpr int Q = q;
-    if constexpr (Q < NPR) {
-      split_pair(a0[2 * Q], a0[2 * Q + 1], A0.hi[LL - 1][Q], A0.lo[LL - 1][Q]);
-      split_pair(a1[2 * Q], a1[2 * Q + 1], A1.hi[LL - 1][Q], A1.lo[LL - 1][Q]);
-    } else {
-      A0.hi[LL - 1][Q] = 0u; A0.lo[LL - 1][Q] = 0u;
-      A1.hi[LL - 1][Q] = 0u; A1.lo[LL - 1][Q] = 0u;
-    }
-  });
-  PF_STAGE();
-}
-
-// weights of one hidden layer as a wave reads them from the LDS image: bias vector (initial accumulator) and the
-// split A operands of both k-steps.  Loaded one phase AHEAD of their use (before the tanh stages of the previous
-// layer), so that the LDS latency hides behind the transcendentals instead of stalling the matrix products.
-struct LayerW {
-  float4 b[4];
-  h8 ahi[KS], alo[KS];
-};
-template <int LL, bool BWDOP>
-__device__ __forceinline__ void load_layer(const unsigned char* __restrict__ img, int lane, LayerW& w) {
-  const int h = lane >> 5;
-  if constexpr (!BWDOP) {
-    const float4* __restrict__ bias = reinterpret_cast<const float4*>(img + pf_n32_off_bias(LL)) + h * 4;
-    w.b[0] = bias[0]; w.b[1] = bias[1]; w.b[2] = bias[2]; w.b[3] = bias[3];
-  }
-  const h8* __restrict__ af = reinterpret_cast<const h8*>(img + (BWDOP ? pf_n32_off_ab(LL) : pf_n32_off_af(LL))) + lane;
-  sfor<0, KS>([&](auto s) { constexpr int S = s; w.ahi[S] = af[(0 * 2 + S) * 64]; w.alo[S] = af[(1 * 2 + S) * 64]; });
-}
-__device__ __forceinline__ f32x16 bias_acc(const LayerW& w) {
-  return f32x16{w.b[0].x, w.b[0].y, w.b[0].z, w.b[0].w, w.b[1].x, w.b[1].y, w.b[1].z, w.b[1].w,
-                w.b[2].x, w.b[2].y, w.b[2].z, w.b[2].w, w.b[3].x, w.b[3].y, w.b[3].z, w.b[3].w};
-}
-// the output unit's weights of this lane's units: wo[2r+h], r < NR
-__device__ __forceinline__ void load_wo(const unsigned char* __restrict__ img, int lane, float (&wv)[16]) {
-  const float4* __restrict__ wo = reinterpret_cast<const float4*>(img + pf_n32_off_wo()) + (lane >> 5) * 4;
-  sfor<0, (NR + 3) / 4>([&](auto q) {
-    constexpr int Q = q;
-    const float4 w = wo[Q];
-    wv[4 * Q] = w.x; wv[4 * Q + 1] = w.y; wv[4 * Q + 2] = w.z; wv[4 * Q + 3] = w.w;
-  });
-}
 template <int IN>
 __device__ __forceinline__ float layer1_row(const float4& w, const float (&x)[3]) {
   // layer 1 on the vector ALU in float, the reference's order: bias, then the inputs ascending
@@ -252,123 +156,6 @@ __device__ __forceinline__ float layer1_row(const float4& w, const float (&x)[3]
     c = fmaf(w.y, x[1], c);
   }
   return c;
-}
-
-// forward through the hidden layers for BOTH tiles of a task; x0 / x1 = (load factor, coordinates) of the tile's
-// element on this lane's column.  p0 / p1: this lane's partial sums of the output unit, KA * sum_r wo[2r+h] a_L[2r+h].
-template <int L, int IN, bool BWD>
-__device__ __forceinline__ void forward_tiles(const unsigned char* __restrict__ img, int lane, const float (&x0)[3],
-                                              const float (&x1)[3], TileAct<L, BWD>& A0, TileAct<L, BWD>& A1,
-                                              float& p0, float& p1, int dbg = 0, int grp = -1) {
-  const int h = lane >> 5;
-  constexpr float C2 = 2.8853900817779268f;   // 2 log2(e)
-  LayerW wl[L > 1 ? L - 1 : 1];
-  float wv[16];
-  {
-    const float4* __restrict__ w1 = reinterpret_cast<const float4*>(img + pf_n32_off_w1());
-    float4 w1v[NR];
-    sfor<0, NR>([&](auto r) { constexpr int R = r; w1v[R] = w1[R * 2 + h]; });
-    if constexpr (L >= 2) load_layer<2, false>(img, lane, wl[0]);
-    else load_wo(img, lane, wv);
-    float z0[NR], z1[NR];
-    sfor<0, NR>([&](auto r) {
-      constexpr int R = r;
-      z0[R] = layer1_row<IN>(w1v[R], x0);
-      z1[R] = layer1_row<IN>(w1v[R], x1);
-    });
-    activate2<L, BWD, 1>(A0, A1, z0, z1, C2, dbg);
-  }
-  if (grp == 1) __builtin_amdgcn_s_barrier();      // lockstep point of wave group 1 (see k_net32_forward)
-  // hidden layers 2..L on the matrix cores: z' = KA KW z, bias as the initial accumulator
-  sfor<2, L + 1>([&](auto l) {
-    constexpr int LL = l;
-    const LayerW& w = wl[LL - 2];
-    f32x16 acc0 = bias_acc(w), acc1 = acc0;
-    if (!(dbg & 8)) {
-      sfor<0, KS>([&](auto s) {
-        constexpr int S = s;
-        acc0 = mfma3(acc0, w.ahi[S], w.alo[S],
-                     as_h8(A0.hi[LL - 2][4 * S], A0.hi[LL - 2][4 * S + 1], A0.hi[LL - 2][4 * S + 2], A0.hi[LL - 2][4 * S + 3]),
-                     as_h8(A0.lo[LL - 2][4 * S], A0.lo[LL - 2][4 * S + 1], A0.lo[LL - 2][4 * S + 2], A0.lo[LL - 2][4 * S + 3]));
-      });
-      sfor<0, KS>([&](auto s) {
-        constexpr int S = s;
-        acc1 = mfma3(acc1, w.ahi[S], w.alo[S],
-                     as_h8(A1.hi[LL - 2][4 * S], A1.hi[LL - 2][4 * S + 1], A1.hi[LL - 2][4 * S + 2], A1.hi[LL - 2][4 * S + 3]),
-                     as_h8(A1.lo[LL - 2][4 * S], A1.lo[LL - 2][4 * S + 1], A1.lo[LL - 2][4 * S + 2], A1.lo[LL - 2][4 * S + 3]));
-      });
-    }
-    // next phase's weights leave now, behind the matrix products and ahead of the tanh stages
-    if constexpr (LL < L) load_layer<LL + 1, false>(img, lane, wl[LL - 1]);
-    else load_wo(img, lane, wv);
-    float z0[NR], z1[NR];
-    sfor<0, NR>([&](auto r) { constexpr int R = r; z0[R] = acc0[R]; z1[R] = acc1[R]; });
-    activate2<L, BWD, LL>(A0, A1, z0, z1, C2 / (PF_N32_KA * PF_N32_KW), dbg);
-  });
-  if (grp == 2) __builtin_amdgcn_s_barrier();
-  p0 = 0.f;
-  p1 = 0.f;
-  sfor<0, NR>([&](auto r) {
-    constexpr int R = r;
-    p0 = fmaf(wv[R], A0.aL[R], p0);
-    p1 = fmaf(wv[R], A1.aL[R], p1);
-  });
-}
-
-// tanh of the NR pre-activations of ONE tile (backward recompute): same stages as activate2
-template <int L, int LL>
-__device__ __forceinline__ void activate1(TileAct<L, true>& A, const float (&z)[NR], float cz) {
-  float e[NR];
-  PF_STAGE();
-  sfor<0, NR>([&](auto r) { constexpr int R = r; e[R] = __builtin_amdgcn_exp2f(z[R] * cz); });
-  PF_STAGE();
-  sfor<0, NR>([&](auto r) { constexpr int R = r; e[R] = __builtin_amdgcn_rcpf(e[R] + 1.0f); });
-  PF_STAGE();
-  float a[2 * NPR];
-  sfor<0, NR>([&](auto r) {
-    constexpr int R = r;
-    a[R] = fmaf(-2.0f * PF_N32_KA, e[R], PF_N32_KA);
-    A.t[LL - 1][R] = fmaf(-e[R], e[R], e[R]);
-    if constexpr (LL == L) A.aL[R] = a[R];
-  });
-  if constexpr (NR & 1) a[NR] = 0.f;
-  sfor<0, NPK>([&](auto q) {
-    constexpr int Q = q;
-    if constexpr (Q < NPR) split_pair(a[2 * Q], a[2 * Q + 1], A.hi[LL - 1][Q], A.lo[LL - 1][Q]);
-    else { A.hi[LL - 1][Q] = 0u; A.lo[LL - 1][Q] = 0u; }
-  });
-  PF_STAGE();
-}
-
-// hidden layers of ONE tile, no output unit: what the backward pass needs (activations and their derivatives).
-// Weights are read from the LDS image where they are used: this kernel lives on its register budget (three waves
-// per SIMD), and with three waves a SIMD hides the LDS latency by itself.
-template <int L, int IN>
-__device__ __forceinline__ void recompute_tile(const unsigned char* __restrict__ img, int lane, const float (&x)[3],
-                                               TileAct<L, true>& A) {
-  const int h = lane >> 5;
-  constexpr float C2 = 2.8853900817779268f;
-  {
-    const float4* __restrict__ w1 = reinterpret_cast<const float4*>(img + pf_n32_off_w1());
-    float z[NR];
-    sfor<0, NR>([&](auto r) { constexpr int R = r; z[R] = layer1_row<IN>(w1[R * 2 + h], x); });
-    activate1<L, 1>(A, z, C2);
-  }
-  sfor<2, L + 1>([&](auto l) {
-    constexpr int LL = l;
-    LayerW w;
-    load_layer<LL, false>(img, lane, w);
-    f32x16 acc = bias_acc(w);
-    sfor<0, KS>([&](auto s) {
-      constexpr int S = s;
-      acc = mfma3(acc, w.ahi[S], w.alo[S],
-                  as_h8(A.hi[LL - 2][4 * S], A.hi[LL - 2][4 * S + 1], A.hi[LL - 2][4 * S + 2], A.hi[LL - 2][4 * S + 3]),
-                  as_h8(A.lo[LL - 2][4 * S], A.lo[LL - 2][4 * S + 1], A.lo[LL - 2][4 * S + 2], A.lo[LL - 2][4 * S + 3]));
-    });
-    float z[NR];
-    sfor<0, NR>([&](auto r) { constexpr int R = r; z[R] = acc[R]; });
-    activate1<L, LL>(A, z, C2 / (PF_N32_KA * PF_N32_KW));
-  });
 }
 
 template <int IN>
@@ -388,175 +175,6 @@ __device__ __forceinline__ void copy_image(unsigned char* dst, const unsigned ch
   const uint4* __restrict__ s = reinterpret_cast<const uint4*>(src);
   uint4* d = reinterpret_cast<uint4*>(dst);
   for (int i = threadIdx.x; i < bytes / 16; i += blockDim.x) d[i] = s[i];
-}
-
-// ---- forward kernel ----------------------------------------------------------------------------------------
-// One block of 16 waves per CU (four per SIMD); every wave walks 64-element tasks, the block in rounds of 16 tasks.
-// The SIMD arbitrates its waves by age: left alone the oldest runs nearly unimpeded, the waves of a SIMD finish far
-// apart (measured: 26 ... 71 us for equal work) and the tail runs on one wave per SIMD.  ONE s_barrier per task
-// keeps the block's waves within a task of each other; the four wave groups (wave >> 2: one wave per SIMD each)
-// pass it at four different places of the task body, so the waves of a SIMD stay a quarter task out of phase
-// instead of reaching their transcendental, matrix and LDS phases together (MI355X_MICROARCH.md, two waves per
-// SIMD, item 9).  Lanes past the end work on the last element again (same inputs, same value) and do not store.
-constexpr int FW_THREADS = 1024;
-
-template <int L, int IN>
-__global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg_arg, int ws) {
-  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
-  extern __shared__ __align__(16) unsigned char smem[];
-  const pf_net net = P.net[which];
-  copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), pf_n32_bytes(L));
-  float* __restrict__ out = which == 0 ? P.prop_e : P.prop_a;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  const int grp = (dbg & 32) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // provably wave-uniform
-  const int n = P.mesh.n_elems;
-  const int ntasks = (n + 63) >> 6;
-  const int per_round = gridDim.x * waves;
-  const int rounds = (ntasks + per_round - 1) / per_round;        // block-uniform trip count: equal barrier counts
-  int task = blockIdx.x * waves + wv;
-  float xn[3];
-  // ws: this launch also writes the element stiffness from both properties: the other property and the element length
-  // travel with the coordinates, one round ahead (loaded where they are used they cost a global round trip per round)
-  const pf_net onet = P.net[1 - which];
-  const float* __restrict__ oprop = which == 0 ? P.prop_a : P.prop_e;
-  float on = onet.scale, l0n = 1.0f;
-  if (n > 0) {
-    const int e0 = min(task * 64 + lane, n - 1);
-    load_x<IN>(xn, P, e0);
-    if (ws) {
-      if (onet.enabled) on = oprop[e0];
-      l0n = P.mesh.egeo[4 * (size_t)e0 + 3];
-    }
-  }
-  // the stop flag, one read per block (the bookkeeping that raises it may run beside this launch: a block whose waves
-  // disagreed would part ways before the lockstep barriers below)
-  __shared__ int s_done;
-  if (threadIdx.x == 0) s_done = P.state->done;
-  __syncthreads();
-  if (s_done || n <= 0) return;
-  const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
-  unsigned long long st0 = 0, sr0 = 0;
-  if (dbg & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
-  for (int r = 0; r < rounds; ++r, task += per_round) {
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    const int e = task * 64 + lane;
-    float x0[3], x1[3];
-    sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
-    const float o = on, l0 = l0n;
-    if (r + 1 < rounds) {
-      const int en = min(e + per_round * 64, n - 1);
-      load_x<IN>(xn, P, en);
-      if (ws) {
-        if (onet.enabled) on = oprop[en];
-        l0n = P.mesh.egeo[4 * (size_t)en + 3];
-      }
-    }
-    TileAct<L, false> A0, A1;
-    float p0, p1;
-    forward_tiles<L, IN, false>(smem, lane, x0, x1, A0, A1, p0, p1, dbg, grp);
-    const float z = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo;
-    if (e < n) {
-      const float v = (net.positive ? pf_softplus(z) : z) * net.scale;
-      out[e] = v;
-      // element stiffness for the node kernels: (young * area) / l0, nn_assembly.py:74 (2-D), :37 (1-D)
-      if (ws) P.elem_s[e] = (which == 0 ? v * o : o * v) / l0;
-    }
-    if (grp == 3) __builtin_amdgcn_s_barrier();
-  }
-  if ((dbg & 16) && lane == 0) {   // diagnostic build only: per-wave stamps into the (unused here) partial-sum workspace
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(P.partials) + (size_t)(blockIdx.x * waves + wv) * 4 + (size_t)which * 65536;
-    d[0] = sr0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = __builtin_amdgcn_s_memtime() - st0;
-    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    d[3] = ((unsigned long long)rounds << 48) | ((unsigned long long)(xcc & 0xf) << 32) | hwid;
-  }
-}
-
-// ---- backward kernel ---------------------------------------------------------------------------------------
-// LDS per wave: two regions, A side (rows d_l of a gradient tile) and B side (columns a_{l-1}; the inputs image of the
-// first layer's tile aliases it: its other columns then hold stale activations, which only reach tile entries that are
-// never written out).  A region holds, per split (hi, lo), the registers 0..7 of every lane ("chunk 0", 16 B per lane
-// at lane*16 + (lane>>5)*64) and the registers 8..15 ("chunk 1").  COMPACT layout (PF_NR <= 12): chunk 1 keeps only
-// registers 8..11 (8 B per lane, [element/4][half-wave][element%4]), column quad 12..15 is read from a constant block
-// (zeros; for the hi image of the B side the block that carries KA in column 15 = the bias column of the tile).
-// All strides are chosen so that the 16-B / 8-B writes and the transposed 8-B reads touch every bank once:
-// a 32-lane half reads 16 pieces of chunk 0 in [c, c+128), 8 of chunk 1 in [c+128, c+192) and 8 of the constant block
-// in [c+192, c+256) (mod 256 B), c = 128*(lane>>5) + 64*(read half).
-constexpr bool COMPACT = NR <= 12;
-constexpr int SP_STRIDE = COMPACT ? 1792 : 2304;      // hi image -> lo image
-constexpr int C1_OFF = 1152;                          // chunk 0 -> chunk 1
-constexpr int REGION = COMPACT ? 3584 : 4608;
-constexpr int WAVE_SCRATCH = 2 * REGION;
-// Constant blocks (512 B each, all = 192 mod 256) sit at the SAME distances from each other as the images they
-// complete: zero block Z at +192 (A hi), Z + SP_STRIDE (A lo), Z + REGION = bias block (B hi), Z + REGION + SP_STRIDE
-// (B lo).  Every lane therefore reads all four operands at ONE per-lane base plus compile-time offsets.
-constexpr int CONST_BYTES = COMPACT ? 6144 : 256;
-// Waves per block (one block per CU) and the shape of the recompute.  Without pairing: as many waves as the kernel's
-// registers allow without spilling (ScratchSize 0 in the compiler's asm for every bucket) — 16 (four per SIMD, 128
-// registers) with one hidden layer, 12 with two, else 8.  A spill reload inside the task loop is followed by
-// s_waitcnt vmcnt(0), which also waits for the NEXT task's prefetched gathers: a spilling 12-wave variant ran slower
-// than the 8-wave one — hence the single per-lane LDS base (operand_base / write_base) and the SGPR-held block-uniform
-// scalars.  Going from 8 to 12 waves did NOT change the kernel time, though: the kernel is not short of waves.
-// PAIRED recompute: both tiles of a task go through the hidden layers together (forward_tiles, the forward kernel's
-// routine: twice the independent work in every MFMA / tanh / split phase) and only the back-propagation runs tile by
-// tile.  That needs ~200 registers, i.e. 8 waves per CU instead of 12 — and is FASTER (same box, 10^6 elements: E net
-// 51.6 -> 50.0 us, A net 40.0 -> 38.4 us): instruction-level parallelism inside a wave hides the MFMA -> tanh -> split
-// -> MFMA dependency chain better than a third wave does.  Used where it compiles without spills (ScratchSize 0 in
-// every bucket): two hidden layers, or three with PF_NR <= 8; one hidden layer keeps the per-tile form at 16 waves.
-template <int L>
-constexpr bool bw_pair() { return L == 2 || (L == 3 && NR <= 8); }
-template <int L, bool GEA>
-constexpr int bw_threads() {
-  if (bw_pair<L>()) return 512;
-  return !COMPACT ? 512 : (L == 1 ? 1024 : (L == 2 && !(GEA && NR > 10) ? 768 : 512));
-}
-
-// lane's pairs (hi or lo) of registers 0..15 -> split `sp` of the region at byte offset `reg` of the wave scratch.
-// wr0 / wr1: the lane's write positions of chunk 0 / chunk 1 in the A region's hi image (write_base).  bias_col: wide
-// layout only, B side hi image: the lane's register 15 carries the bias column's KA (lower half-wave)
-struct WriteBase { unsigned char* c0; unsigned char* c1; };
-__device__ __forceinline__ WriteBase write_base(unsigned char* scratch, int lane) {
-  const int hs = lane >> 5, e = lane & 31;
-  WriteBase w;
-  w.c0 = scratch + hs * 576 + e * 16;
-  w.c1 = COMPACT ? scratch + C1_OFF + 64 * (e >> 2) + 32 * hs + 8 * (e & 3) : scratch + C1_OFF + hs * 576 + e * 16;
-  return w;
-}
-template <int REG, int SP>
-__device__ __forceinline__ void write_rows(const WriteBase& wb, int lane, const unsigned (&pk)[NPK], bool bias_col = false) {
-  constexpr int OFF = REG + SP * SP_STRIDE;
-  *reinterpret_cast<u32x4*>(wb.c0 + OFF) = u32x4{pk[0], pk[1], pk[2], pk[3]};
-  if constexpr (!COMPACT) {
-    const unsigned k7 = pk[7] | ((bias_col && (lane >> 5) == 0) ? (BF ? 0x45000000u : 0x68000000u) : 0u);   // 2048.0 (bf16 / f16) in the high half
-    *reinterpret_cast<u32x4*>(wb.c1 + OFF) = u32x4{pk[4], pk[5], pk[6], k7};
-  } else if constexpr (NR > 8) {
-    *reinterpret_cast<u32x2*>(wb.c1 + OFF) = u32x2{pk[4], pk[5]};
-  }
-}
-
-// Per-lane base address of the transposed operand reads of one image (cdna_hip_programming.md T10): group g = lane>>4
-// reads the 4x16 block rows (elements) e0..e0+3, columns 16*(g&1)..+15; lane 4q+p of the group supplies the address of
-// row q, columns 4p..4p+3.  The element part 16*e0 = 256*ks + 64*half (+128*(lane>>5), folded in here) is the same for
-// every lane, so the reads of a tile use immediate offsets.
-__device__ __forceinline__ const unsigned char* operand_base(const unsigned char* scratch, int lane,
-                                                             const unsigned char* zblock) {
-  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-  const int hsrc = g & 1, hl = g >> 1;
-  const unsigned char* a;
-  if constexpr (COMPACT) {
-    a = p < 2 ? scratch + hsrc * 576 + q * 16 + 8 * (p & 1)
-              : (p == 2 ? scratch + C1_OFF + 32 * hsrc + 8 * q : zblock + 32 * hsrc + 8 * q);
-  } else {
-    a = scratch + (p >> 1) * C1_OFF + hsrc * 576 + q * 16 + 8 * (p & 1);
-  }
-  return a + 128 * hl;
-}
-template <int OFF>
-__device__ __forceinline__ h8 read_operand(const unsigned char* base, int ks) {
-  const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + OFF + 256 * ks));
-  const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + OFF + 256 * ks + 64));
-  typedef short s8v __attribute__((ext_vector_type(8)));
-  return __builtin_bit_cast(h8, s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 
 template <int DIM>
@@ -612,112 +230,505 @@ __device__ __forceinline__ float task_gea(const TaskIn<DIM>& t, int fe_mode) {
   return gs / t.g.l0;
 }
 
-// backward of one tile: d_L from g_z S, back-propagation, and the tile's contribution to the gradient products
-// T[0] = combined tile (rows d_1, columns inputs), T[l-1] = rows d_l, columns a_{l-1} (l = 2..L).
-// wv: wo of this lane's units; wb: transposed operands of layer L (both loaded by recompute_tile).
-template <int L, int IN>
-__device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ img, unsigned char* scratch, int lane,
-                                              const TileAct<L, true>& A, float gs /* g_z S of the column's element */,
-                                              const unsigned (&xhi)[NPK], const unsigned (&xlo)[NPK],
-                                              f32x16 (&T)[L], const WriteBase& wb,
-                                              const unsigned char* rd /* operand_base: A hi; A lo, B hi, B lo at fixed offsets */,
-                                              int dbg = 0) {
-  const int h = lane >> 5;
-  // d_L[r] = (4 wo[2r+h] g_z S) t_L[r]
-  float d[2 * NPR];
-  {
-    float wv[16];
-    load_wo(img, lane, wv);
-    const float g4 = 4.0f * gs;
-    sfor<0, NR>([&](auto r) { constexpr int R = r; d[R] = (wv[R] * g4) * A.t[L - 1][R]; });
-    if constexpr (NR & 1) d[NR] = 0.f;
-  }
-  sfor<0, L>([&](auto s) {
-    constexpr int LL = L - s;          // L .. 1: d holds d_LL (scaled by S 4^(L-LL))
-    unsigned dhi[NPK], dlo[NPK];
+// ---- everything that depends on the register bucket NR (registers per lane that carry real units: nets of width <= 2 NR)
+// lives in one class template, so that one kernel can run nets of two different buckets (the fused E + A launches)
+template <int NR_>
+struct Eng {
+  static constexpr int NR = NR_;            // accumulator registers per lane that carry real units
+  static constexpr int KS = NR > 8 ? 2 : 1;  // k-steps of 16 units
+  static constexpr int NPK = 4 * KS;         // packed f16 pairs per operand set (pairs >= (NR+1)/2 are zero)
+  static constexpr int NPR = (NR + 1) / 2;   // pairs that carry data
+  static_assert(NR >= 1 && NR <= 15, "register bucket out of range");
+
+  // ---- activations of one tile kept for the backward pass -------------------------------------------------
+  template <int L, bool BWD>
+  struct TileAct {
+    unsigned hi[L][NPK], lo[L][NPK];   // a'_l = KA tanh(z_l) as packed f16 pairs (pair q = registers 2q, 2q+1)
+    float t[BWD ? L : 1][NR];          // r (1 - r) with tanh = 1 - 2 r: (1 - tanh^2) / 4
+    float aL[NR];                      // a'_L in float (output unit and its gradient)
+  };
+
+  // Scheduling fence.  Left alone, hipcc serialises each unit's exp -> add -> rcp -> fma chain (the transcendental
+  // results are needed a few cycles after issue, so the wave stalls on every step); the stages below issue one kind
+  // of instruction for all units of both tiles back to back, which hides those latencies inside the wave.
+#define PF_STAGE() __builtin_amdgcn_sched_barrier(0)
+
+  // tanh of the NR pre-activations z[r] * cz of BOTH tiles; writes the packed pairs (and t, aL) of layer LL
+  template <int L, bool BWD, int LL>
+  static __device__ __forceinline__ void activate2(TileAct<L, BWD>& A0, TileAct<L, BWD>& A1, const float (&z0)[NR],
+                                            const float (&z1)[NR], float cz, int dbg = 0) {
+    float e0[NR], e1[NR];
+    PF_STAGE();
+    if (dbg & 4) {   // timing experiment: no transcendentals
+      sfor<0, NR>([&](auto r) { constexpr int R = r; e0[R] = z0[R] * cz; e1[R] = z1[R] * cz; });
+    } else {
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      e0[R] = __builtin_amdgcn_exp2f(z0[R] * cz);
+      e1[R] = __builtin_amdgcn_exp2f(z1[R] * cz);
+    });
+    PF_STAGE();
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      e0[R] = __builtin_amdgcn_rcpf(e0[R] + 1.0f);
+      e1[R] = __builtin_amdgcn_rcpf(e1[R] + 1.0f);
+    });
+    }
+    PF_STAGE();
+    float a0[2 * NPR], a1[2 * NPR];
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      a0[R] = fmaf(-2.0f * PF_N32_KA, e0[R], PF_N32_KA);
+      a1[R] = fmaf(-2.0f * PF_N32_KA, e1[R], PF_N32_KA);
+      if constexpr (BWD) {
+        A0.t[LL - 1][R] = fmaf(-e0[R], e0[R], e0[R]);
+        A1.t[LL - 1][R] = fmaf(-e1[R], e1[R], e1[R]);
+      }
+      if constexpr (LL == L) { A0.aL[R] = a0[R]; A1.aL[R] = a1[R]; }
+    });
+    if constexpr (NR & 1) { a0[NR] = 0.f; a1[NR] = 0.f; }
     sfor<0, NPK>([&](auto q) {
       constexpr int Q = q;
-      if constexpr (Q < NPR) split_pair(d[2 * Q], d[2 * Q + 1], dhi[Q], dlo[Q]);
-      else { dhi[Q] = 0u; dlo[Q] = 0u; }
-    });
-    // Order of issue (a wave issues in order, so this order IS the overlap): the LDS writes of the gradient tile's
-    // operands, the weights and ALL transposed reads, then the back-propagation products — whose 6 x 32 matrix cycles
-    // cover the LDS write -> transposed read latency — and only then the tile products that consume the reads.
-    // (Back-propagation first and the LDS round trip after it left ~200-300 cycles exposed per layer and tile.)
-    f32x16 acc = zero16();
-    LayerW w;
-    if constexpr (LL >= 2) load_layer<LL, true>(img, lane, w);
-    h8 ahi[2], alo[2], bhi[2], blo[2];
-    if (!(dbg & 1)) {
-      // gradient tile of layer LL: rows d_LL through LDS; columns a_{LL-1} (LL >= 2) or the inputs (LL == 1)
-      write_rows<0, 0>(wb, lane, dhi);
-      if constexpr (!BF) write_rows<0, 1>(wb, lane, dlo);
-      if constexpr (LL >= 2) {
-        write_rows<REGION, 0>(wb, lane, A.hi[LL - 2], true);
-        if constexpr (!BF) write_rows<REGION, 1>(wb, lane, A.lo[LL - 2]);
+      if constexpr (Q < NPR) {
+        split_pair(a0[2 * Q], a0[2 * Q + 1], A0.hi[LL - 1][Q], A0.lo[LL - 1][Q]);
+        split_pair(a1[2 * Q], a1[2 * Q + 1], A1.hi[LL - 1][Q], A1.lo[LL - 1][Q]);
       } else {
-        // inputs of the element: registers 0..3 of the lower half-wave's slot (columns 0..3) of the B region
-        // (for h == 0 the chunk-0 position IS lane * 16)
-        if (h == 0) {
-          *reinterpret_cast<u32x2*>(wb.c0 + REGION) = u32x2{xhi[0], xhi[1]};
-          if constexpr (!BF) *reinterpret_cast<u32x2*>(wb.c0 + REGION + SP_STRIDE) = u32x2{xlo[0], xlo[1]};
-        }
+        A0.hi[LL - 1][Q] = 0u; A0.lo[LL - 1][Q] = 0u;
+        A1.hi[LL - 1][Q] = 0u; A1.lo[LL - 1][Q] = 0u;
       }
-      // the wave's own LDS writes are visible to its own later reads (in-order); tell the compiler only
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // inputs tile (LL == 1): its B hi image has no bias column (the element's inputs carry their own 1.0), so the
-      // lanes that read column quad 12..15 take the ZERO block (their base, as it is) instead of the bias block
-      const unsigned char* rdb = rd;
-      if constexpr (LL == 1 && COMPACT) rdb = ((lane & 3) == 3) ? rd - REGION : rd;
-      auto read_all = [&]() {
-        sfor<0, 2>([&](auto ks) {
-          constexpr int S = ks;
-          ahi[S] = read_operand<0>(rd, S);
-          bhi[S] = read_operand<REGION>(rdb, S);
-          alo[S] = ahi[S]; blo[S] = bhi[S];     // (unused with plain bf16 operands)
-          if constexpr (!BF) { alo[S] = read_operand<SP_STRIDE>(rd, S); blo[S] = read_operand<REGION + SP_STRIDE>(rd, S); }
+    });
+    PF_STAGE();
+  }
+
+  // weights of one hidden layer as a wave reads them from the LDS image: bias vector (initial accumulator) and the
+  // split A operands of both k-steps.  Loaded one phase AHEAD of their use (before the tanh stages of the previous
+  // layer), so that the LDS latency hides behind the transcendentals instead of stalling the matrix products.
+  struct LayerW {
+    float4 b[4];
+    h8 ahi[KS], alo[KS];
+  };
+  template <int LL, bool BWDOP>
+  static __device__ __forceinline__ void load_layer(const unsigned char* __restrict__ img, int lane, LayerW& w) {
+    const int h = lane >> 5;
+    if constexpr (!BWDOP) {
+      const float4* __restrict__ bias = reinterpret_cast<const float4*>(img + pf_n32_off_bias(LL)) + h * 4;
+      w.b[0] = bias[0]; w.b[1] = bias[1]; w.b[2] = bias[2]; w.b[3] = bias[3];
+    }
+    const h8* __restrict__ af = reinterpret_cast<const h8*>(img + (BWDOP ? pf_n32_off_ab(LL) : pf_n32_off_af(LL))) + lane;
+    sfor<0, KS>([&](auto s) { constexpr int S = s; w.ahi[S] = af[(0 * 2 + S) * 64]; w.alo[S] = af[(1 * 2 + S) * 64]; });
+  }
+  static __device__ __forceinline__ f32x16 bias_acc(const LayerW& w) {
+    return f32x16{w.b[0].x, w.b[0].y, w.b[0].z, w.b[0].w, w.b[1].x, w.b[1].y, w.b[1].z, w.b[1].w,
+                  w.b[2].x, w.b[2].y, w.b[2].z, w.b[2].w, w.b[3].x, w.b[3].y, w.b[3].z, w.b[3].w};
+  }
+  // the output unit's weights of this lane's units: wo[2r+h], r < NR
+  static __device__ __forceinline__ void load_wo(const unsigned char* __restrict__ img, int lane, float (&wv)[16]) {
+    const float4* __restrict__ wo = reinterpret_cast<const float4*>(img + pf_n32_off_wo()) + (lane >> 5) * 4;
+    sfor<0, (NR + 3) / 4>([&](auto q) {
+      constexpr int Q = q;
+      const float4 w = wo[Q];
+      wv[4 * Q] = w.x; wv[4 * Q + 1] = w.y; wv[4 * Q + 2] = w.z; wv[4 * Q + 3] = w.w;
+    });
+  }
+  // forward through the hidden layers for BOTH tiles of a task; x0 / x1 = (load factor, coordinates) of the tile's
+  // element on this lane's column.  p0 / p1: this lane's partial sums of the output unit, KA * sum_r wo[2r+h] a_L[2r+h].
+  template <int L, int IN, bool BWD>
+  static __device__ __forceinline__ void forward_tiles(const unsigned char* __restrict__ img, int lane, const float (&x0)[3],
+                                                const float (&x1)[3], TileAct<L, BWD>& A0, TileAct<L, BWD>& A1,
+                                                float& p0, float& p1, int dbg = 0, int grp = -1) {
+    const int h = lane >> 5;
+    constexpr float C2 = 2.8853900817779268f;   // 2 log2(e)
+    LayerW wl[L > 1 ? L - 1 : 1];
+    float wv[16];
+    {
+      const float4* __restrict__ w1 = reinterpret_cast<const float4*>(img + pf_n32_off_w1());
+      float4 w1v[NR];
+      sfor<0, NR>([&](auto r) { constexpr int R = r; w1v[R] = w1[R * 2 + h]; });
+      if constexpr (L >= 2) load_layer<2, false>(img, lane, wl[0]);
+      else load_wo(img, lane, wv);
+      float z0[NR], z1[NR];
+      sfor<0, NR>([&](auto r) {
+        constexpr int R = r;
+        z0[R] = layer1_row<IN>(w1v[R], x0);
+        z1[R] = layer1_row<IN>(w1v[R], x1);
+      });
+      activate2<L, BWD, 1>(A0, A1, z0, z1, C2, dbg);
+    }
+    if (grp == 1) __builtin_amdgcn_s_barrier();      // lockstep point of wave group 1 (see k_net32_forward)
+    // hidden layers 2..L on the matrix cores: z' = KA KW z, bias as the initial accumulator
+    sfor<2, L + 1>([&](auto l) {
+      constexpr int LL = l;
+      const LayerW& w = wl[LL - 2];
+      f32x16 acc0 = bias_acc(w), acc1 = acc0;
+      if (!(dbg & 8)) {
+        sfor<0, KS>([&](auto s) {
+          constexpr int S = s;
+          acc0 = mfma3(acc0, w.ahi[S], w.alo[S],
+                       as_h8(A0.hi[LL - 2][4 * S], A0.hi[LL - 2][4 * S + 1], A0.hi[LL - 2][4 * S + 2], A0.hi[LL - 2][4 * S + 3]),
+                       as_h8(A0.lo[LL - 2][4 * S], A0.lo[LL - 2][4 * S + 1], A0.lo[LL - 2][4 * S + 2], A0.lo[LL - 2][4 * S + 3]));
         });
-      };
-      // (the wide layout with three hidden layers has no registers left for 16 reads in flight across the products:
-      //  there the reads follow the back-propagation, as they used to)
-      constexpr bool EARLY = COMPACT || L < 3;
-      if constexpr (EARLY) {
-        read_all();
-        PF_STAGE();
+        sfor<0, KS>([&](auto s) {
+          constexpr int S = s;
+          acc1 = mfma3(acc1, w.ahi[S], w.alo[S],
+                       as_h8(A1.hi[LL - 2][4 * S], A1.hi[LL - 2][4 * S + 1], A1.hi[LL - 2][4 * S + 2], A1.hi[LL - 2][4 * S + 3]),
+                       as_h8(A1.lo[LL - 2][4 * S], A1.lo[LL - 2][4 * S + 1], A1.lo[LL - 2][4 * S + 2], A1.lo[LL - 2][4 * S + 3]));
+        });
       }
-      // back-propagation to layer LL-1
-      if constexpr (LL >= 2) {
+      // next phase's weights leave now, behind the matrix products and ahead of the tanh stages
+      if constexpr (LL < L) load_layer<LL + 1, false>(img, lane, wl[LL - 1]);
+      else load_wo(img, lane, wv);
+      float z0[NR], z1[NR];
+      sfor<0, NR>([&](auto r) { constexpr int R = r; z0[R] = acc0[R]; z1[R] = acc1[R]; });
+      activate2<L, BWD, LL>(A0, A1, z0, z1, C2 / (PF_N32_KA * PF_N32_KW), dbg);
+    });
+    if (grp == 2) __builtin_amdgcn_s_barrier();
+    p0 = 0.f;
+    p1 = 0.f;
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      p0 = fmaf(wv[R], A0.aL[R], p0);
+      p1 = fmaf(wv[R], A1.aL[R], p1);
+    });
+  }
+
+  // tanh of the NR pre-activations of ONE tile (backward recompute): same stages as activate2
+  template <int L, int LL>
+  static __device__ __forceinline__ void activate1(TileAct<L, true>& A, const float (&z)[NR], float cz) {
+    float e[NR];
+    PF_STAGE();
+    sfor<0, NR>([&](auto r) { constexpr int R = r; e[R] = __builtin_amdgcn_exp2f(z[R] * cz); });
+    PF_STAGE();
+    sfor<0, NR>([&](auto r) { constexpr int R = r; e[R] = __builtin_amdgcn_rcpf(e[R] + 1.0f); });
+    PF_STAGE();
+    float a[2 * NPR];
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      a[R] = fmaf(-2.0f * PF_N32_KA, e[R], PF_N32_KA);
+      A.t[LL - 1][R] = fmaf(-e[R], e[R], e[R]);
+      if constexpr (LL == L) A.aL[R] = a[R];
+    });
+    if constexpr (NR & 1) a[NR] = 0.f;
+    sfor<0, NPK>([&](auto q) {
+      constexpr int Q = q;
+      if constexpr (Q < NPR) split_pair(a[2 * Q], a[2 * Q + 1], A.hi[LL - 1][Q], A.lo[LL - 1][Q]);
+      else { A.hi[LL - 1][Q] = 0u; A.lo[LL - 1][Q] = 0u; }
+    });
+    PF_STAGE();
+  }
+
+  // hidden layers of ONE tile, no output unit: what the backward pass needs (activations and their derivatives).
+  // Weights are read from the LDS image where they are used: this kernel lives on its register budget (three waves
+  // per SIMD), and with three waves a SIMD hides the LDS latency by itself.
+  template <int L, int IN>
+  static __device__ __forceinline__ void recompute_tile(const unsigned char* __restrict__ img, int lane, const float (&x)[3],
+                                                 TileAct<L, true>& A) {
+    const int h = lane >> 5;
+    constexpr float C2 = 2.8853900817779268f;
+    {
+      const float4* __restrict__ w1 = reinterpret_cast<const float4*>(img + pf_n32_off_w1());
+      float z[NR];
+      sfor<0, NR>([&](auto r) { constexpr int R = r; z[R] = layer1_row<IN>(w1[R * 2 + h], x); });
+      activate1<L, 1>(A, z, C2);
+    }
+    sfor<2, L + 1>([&](auto l) {
+      constexpr int LL = l;
+      LayerW w;
+      load_layer<LL, false>(img, lane, w);
+      f32x16 acc = bias_acc(w);
+      sfor<0, KS>([&](auto s) {
+        constexpr int S = s;
+        acc = mfma3(acc, w.ahi[S], w.alo[S],
+                    as_h8(A.hi[LL - 2][4 * S], A.hi[LL - 2][4 * S + 1], A.hi[LL - 2][4 * S + 2], A.hi[LL - 2][4 * S + 3]),
+                    as_h8(A.lo[LL - 2][4 * S], A.lo[LL - 2][4 * S + 1], A.lo[LL - 2][4 * S + 2], A.lo[LL - 2][4 * S + 3]));
+      });
+      float z[NR];
+      sfor<0, NR>([&](auto r) { constexpr int R = r; z[R] = acc[R]; });
+      activate1<L, LL>(A, z, C2 / (PF_N32_KA * PF_N32_KW));
+    });
+  }
+
+  // ---- backward kernel ---------------------------------------------------------------------------------------
+  // LDS per wave: two regions, A side (rows d_l of a gradient tile) and B side (columns a_{l-1}; the inputs image of the
+  // first layer's tile aliases it: its other columns then hold stale activations, which only reach tile entries that are
+  // never written out).  A region holds, per split (hi, lo), the registers 0..7 of every lane ("chunk 0", 16 B per lane
+  // at lane*16 + (lane>>5)*64) and the registers 8..15 ("chunk 1").  COMPACT layout (PF_NR <= 12): chunk 1 keeps only
+  // registers 8..11 (8 B per lane, [element/4][half-wave][element%4]), column quad 12..15 is read from a constant block
+  // (zeros; for the hi image of the B side the block that carries KA in column 15 = the bias column of the tile).
+  // All strides are chosen so that the 16-B / 8-B writes and the transposed 8-B reads touch every bank once:
+  // a 32-lane half reads 16 pieces of chunk 0 in [c, c+128), 8 of chunk 1 in [c+128, c+192) and 8 of the constant block
+  // in [c+192, c+256) (mod 256 B), c = 128*(lane>>5) + 64*(read half).
+  static constexpr bool COMPACT = NR <= 12;
+  static constexpr int SP_STRIDE = COMPACT ? 1792 : 2304;      // hi image -> lo image
+  static constexpr int C1_OFF = 1152;                          // chunk 0 -> chunk 1
+  static constexpr int REGION = COMPACT ? 3584 : 4608;
+  static constexpr int WAVE_SCRATCH = 2 * REGION;
+  // Constant blocks (512 B each, all = 192 mod 256) sit at the SAME distances from each other as the images they
+  // complete: zero block Z at +192 (A hi), Z + SP_STRIDE (A lo), Z + REGION = bias block (B hi), Z + REGION + SP_STRIDE
+  // (B lo).  Every lane therefore reads all four operands at ONE per-lane base plus compile-time offsets.
+  static constexpr int CONST_BYTES = COMPACT ? 6144 : 256;
+  // Waves per block (one block per CU) and the shape of the recompute.  Without pairing: as many waves as the kernel's
+  // registers allow without spilling (ScratchSize 0 in the compiler's asm for every bucket) — 16 (four per SIMD, 128
+  // registers) with one hidden layer, 12 with two, else 8.  A spill reload inside the task loop is followed by
+  // s_waitcnt vmcnt(0), which also waits for the NEXT task's prefetched gathers: a spilling 12-wave variant ran slower
+  // than the 8-wave one — hence the single per-lane LDS base (operand_base / write_base) and the SGPR-held block-uniform
+  // scalars.  Going from 8 to 12 waves did NOT change the kernel time, though: the kernel is not short of waves.
+  // PAIRED recompute: both tiles of a task go through the hidden layers together (forward_tiles, the forward kernel's
+  // routine: twice the independent work in every MFMA / tanh / split phase) and only the back-propagation runs tile by
+  // tile.  That needs ~200 registers, i.e. 8 waves per CU instead of 12 — and is FASTER (same box, 10^6 elements: E net
+  // 51.6 -> 50.0 us, A net 40.0 -> 38.4 us): instruction-level parallelism inside a wave hides the MFMA -> tanh -> split
+  // -> MFMA dependency chain better than a third wave does.  Used where it compiles without spills (ScratchSize 0 in
+  // every bucket): two hidden layers, or three with PF_NR <= 8; one hidden layer keeps the per-tile form at 16 waves.
+  template <int L>
+  static constexpr bool bw_pair() { return L == 2 || (L == 3 && NR <= 8); }
+  template <int L, bool GEA>
+  static constexpr int bw_threads() {
+    if (bw_pair<L>()) return 512;
+    return !COMPACT ? 512 : (L == 1 ? 1024 : (L == 2 && !(GEA && NR > 10) ? 768 : 512));
+  }
+
+  // lane's pairs (hi or lo) of registers 0..15 -> split `sp` of the region at byte offset `reg` of the wave scratch.
+  // wr0 / wr1: the lane's write positions of chunk 0 / chunk 1 in the A region's hi image (write_base).  bias_col: wide
+  // layout only, B side hi image: the lane's register 15 carries the bias column's KA (lower half-wave)
+  struct WriteBase { unsigned char* c0; unsigned char* c1; };
+  static __device__ __forceinline__ WriteBase write_base(unsigned char* scratch, int lane) {
+    const int hs = lane >> 5, e = lane & 31;
+    WriteBase w;
+    w.c0 = scratch + hs * 576 + e * 16;
+    w.c1 = COMPACT ? scratch + C1_OFF + 64 * (e >> 2) + 32 * hs + 8 * (e & 3) : scratch + C1_OFF + hs * 576 + e * 16;
+    return w;
+  }
+  template <int REG, int SP>
+  static __device__ __forceinline__ void write_rows(const WriteBase& wb, int lane, const unsigned (&pk)[NPK], bool bias_col = false) {
+    constexpr int OFF = REG + SP * SP_STRIDE;
+    *reinterpret_cast<u32x4*>(wb.c0 + OFF) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+    if constexpr (!COMPACT) {
+      const unsigned k7 = pk[7] | ((bias_col && (lane >> 5) == 0) ? (BF ? 0x45000000u : 0x68000000u) : 0u);   // 2048.0 (bf16 / f16) in the high half
+      *reinterpret_cast<u32x4*>(wb.c1 + OFF) = u32x4{pk[4], pk[5], pk[6], k7};
+    } else if constexpr (NR > 8) {
+      *reinterpret_cast<u32x2*>(wb.c1 + OFF) = u32x2{pk[4], pk[5]};
+    }
+  }
+
+  // Per-lane base address of the transposed operand reads of one image (cdna_hip_programming.md T10): group g = lane>>4
+  // reads the 4x16 block rows (elements) e0..e0+3, columns 16*(g&1)..+15; lane 4q+p of the group supplies the address of
+  // row q, columns 4p..4p+3.  The element part 16*e0 = 256*ks + 64*half (+128*(lane>>5), folded in here) is the same for
+  // every lane, so the reads of a tile use immediate offsets.
+  static __device__ __forceinline__ const unsigned char* operand_base(const unsigned char* scratch, int lane,
+                                                               const unsigned char* zblock) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int hsrc = g & 1, hl = g >> 1;
+    const unsigned char* a;
+    if constexpr (COMPACT) {
+      a = p < 2 ? scratch + hsrc * 576 + q * 16 + 8 * (p & 1)
+                : (p == 2 ? scratch + C1_OFF + 32 * hsrc + 8 * q : zblock + 32 * hsrc + 8 * q);
+    } else {
+      a = scratch + (p >> 1) * C1_OFF + hsrc * 576 + q * 16 + 8 * (p & 1);
+    }
+    return a + 128 * hl;
+  }
+  template <int OFF>
+  static __device__ __forceinline__ h8 read_operand(const unsigned char* base, int ks) {
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + OFF + 256 * ks));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4v*)(base + OFF + 256 * ks + 64));
+    typedef short s8v __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(h8, s8v{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+  }
+
+  // backward of one tile: d_L from g_z S, back-propagation, and the tile's contribution to the gradient products
+  // T[0] = combined tile (rows d_1, columns inputs), T[l-1] = rows d_l, columns a_{l-1} (l = 2..L).
+  // wv: wo of this lane's units; wb: transposed operands of layer L (both loaded by recompute_tile).
+  template <int L, int IN>
+  static __device__ __forceinline__ void backward_tile(const unsigned char* __restrict__ img, unsigned char* scratch, int lane,
+                                                const TileAct<L, true>& A, float gs /* g_z S of the column's element */,
+                                                const unsigned (&xhi)[NPK], const unsigned (&xlo)[NPK],
+                                                f32x16 (&T)[L], const WriteBase& wb,
+                                                const unsigned char* rd /* operand_base: A hi; A lo, B hi, B lo at fixed offsets */,
+                                                int dbg = 0) {
+    const int h = lane >> 5;
+    // d_L[r] = (4 wo[2r+h] g_z S) t_L[r]
+    float d[2 * NPR];
+    {
+      float wv[16];
+      load_wo(img, lane, wv);
+      const float g4 = 4.0f * gs;
+      sfor<0, NR>([&](auto r) { constexpr int R = r; d[R] = (wv[R] * g4) * A.t[L - 1][R]; });
+      if constexpr (NR & 1) d[NR] = 0.f;
+    }
+    sfor<0, L>([&](auto s) {
+      constexpr int LL = L - s;          // L .. 1: d holds d_LL (scaled by S 4^(L-LL))
+      unsigned dhi[NPK], dlo[NPK];
+      sfor<0, NPK>([&](auto q) {
+        constexpr int Q = q;
+        if constexpr (Q < NPR) split_pair(d[2 * Q], d[2 * Q + 1], dhi[Q], dlo[Q]);
+        else { dhi[Q] = 0u; dlo[Q] = 0u; }
+      });
+      // Order of issue (a wave issues in order, so this order IS the overlap): the LDS writes of the gradient tile's
+      // operands, the weights and ALL transposed reads, then the back-propagation products — whose 6 x 32 matrix cycles
+      // cover the LDS write -> transposed read latency — and only then the tile products that consume the reads.
+      // (Back-propagation first and the LDS round trip after it left ~200-300 cycles exposed per layer and tile.)
+      f32x16 acc = zero16();
+      LayerW w;
+      if constexpr (LL >= 2) load_layer<LL, true>(img, lane, w);
+      h8 ahi[2], alo[2], bhi[2], blo[2];
+      if (!(dbg & 1)) {
+        // gradient tile of layer LL: rows d_LL through LDS; columns a_{LL-1} (LL >= 2) or the inputs (LL == 1)
+        write_rows<0, 0>(wb, lane, dhi);
+        if constexpr (!BF) write_rows<0, 1>(wb, lane, dlo);
+        if constexpr (LL >= 2) {
+          write_rows<REGION, 0>(wb, lane, A.hi[LL - 2], true);
+          if constexpr (!BF) write_rows<REGION, 1>(wb, lane, A.lo[LL - 2]);
+        } else {
+          // inputs of the element: registers 0..3 of the lower half-wave's slot (columns 0..3) of the B region
+          // (for h == 0 the chunk-0 position IS lane * 16)
+          if (h == 0) {
+            *reinterpret_cast<u32x2*>(wb.c0 + REGION) = u32x2{xhi[0], xhi[1]};
+            if constexpr (!BF) *reinterpret_cast<u32x2*>(wb.c0 + REGION + SP_STRIDE) = u32x2{xlo[0], xlo[1]};
+          }
+        }
+        // the wave's own LDS writes are visible to its own later reads (in-order); tell the compiler only
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // inputs tile (LL == 1): its B hi image has no bias column (the element's inputs carry their own 1.0), so the
+        // lanes that read column quad 12..15 take the ZERO block (their base, as it is) instead of the bias block
+        const unsigned char* rdb = rd;
+        if constexpr (LL == 1 && COMPACT) rdb = ((lane & 3) == 3) ? rd - REGION : rd;
+        auto read_all = [&]() {
+          sfor<0, 2>([&](auto ks) {
+            constexpr int S = ks;
+            ahi[S] = read_operand<0>(rd, S);
+            bhi[S] = read_operand<REGION>(rdb, S);
+            alo[S] = ahi[S]; blo[S] = bhi[S];     // (unused with plain bf16 operands)
+            if constexpr (!BF) { alo[S] = read_operand<SP_STRIDE>(rd, S); blo[S] = read_operand<REGION + SP_STRIDE>(rd, S); }
+          });
+        };
+        // (the wide layout with three hidden layers has no registers left for 16 reads in flight across the products:
+        //  there the reads follow the back-propagation, as they used to)
+        constexpr bool EARLY = COMPACT || L < 3;
+        if constexpr (EARLY) {
+          read_all();
+          PF_STAGE();
+        }
+        // back-propagation to layer LL-1
+        if constexpr (LL >= 2) {
+          sfor<0, KS>([&](auto ks) {
+            constexpr int S = ks;
+            acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
+                        as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
+          });
+        }
+        if constexpr (!EARLY) read_all();
+        PF_STAGE();
+        sfor<0, 2>([&](auto ks) { constexpr int S = ks; T[LL - 1] = mfma3(T[LL - 1], ahi[S], alo[S], bhi[S], blo[S]); });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      } else if constexpr (LL >= 2) {     // (timing build with the gradient tiles switched off)
         sfor<0, KS>([&](auto ks) {
           constexpr int S = ks;
           acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
                       as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
         });
       }
-      if constexpr (!EARLY) read_all();
-      PF_STAGE();
-      sfor<0, 2>([&](auto ks) { constexpr int S = ks; T[LL - 1] = mfma3(T[LL - 1], ahi[S], alo[S], bhi[S], blo[S]); });
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    } else if constexpr (LL >= 2) {     // (timing build with the gradient tiles switched off)
-      sfor<0, KS>([&](auto ks) {
-        constexpr int S = ks;
-        acc = mfma3(acc, w.ahi[S], w.alo[S], as_h8(dhi[4 * S], dhi[4 * S + 1], dhi[4 * S + 2], dhi[4 * S + 3]),
-                    as_h8(dlo[4 * S], dlo[4 * S + 1], dlo[4 * S + 2], dlo[4 * S + 3]));
-      });
+      if constexpr (LL >= 2) {
+        sfor<0, NR>([&](auto r) { constexpr int R = r; d[R] = acc[R] * A.t[LL - 2][R]; });
+      }
+    });
+  }
+
+};
+
+// ---- forward kernel ----------------------------------------------------------------------------------------
+// One block of 16 waves per CU (four per SIMD); every wave walks 64-element tasks, the block in rounds of 16 tasks.
+// The SIMD arbitrates its waves by age: left alone the oldest runs nearly unimpeded, the waves of a SIMD finish far
+// apart (measured: 26 ... 71 us for equal work) and the tail runs on one wave per SIMD.  ONE s_barrier per task
+// keeps the block's waves within a task of each other; the four wave groups (wave >> 2: one wave per SIMD each)
+// pass it at four different places of the task body, so the waves of a SIMD stay a quarter task out of phase
+// instead of reaching their transcendental, matrix and LDS phases together (MI355X_MICROARCH.md, two waves per
+// SIMD, item 9).  Lanes past the end work on the last element again (same inputs, same value) and do not store.
+constexpr int FW_THREADS = 1024;
+
+template <int NR, int L, int IN>
+__global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg_arg, int ws) {
+  using E = Eng<NR>;
+  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
+  extern __shared__ __align__(16) unsigned char smem[];
+  const pf_net net = P.net[which];
+  copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), pf_n32_bytes(L));
+  float* __restrict__ out = which == 0 ? P.prop_e : P.prop_a;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int grp = (dbg & 32) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // provably wave-uniform
+  const int n = P.mesh.n_elems;
+  const int ntasks = (n + 63) >> 6;
+  const int per_round = gridDim.x * waves;
+  const int rounds = (ntasks + per_round - 1) / per_round;        // block-uniform trip count: equal barrier counts
+  int task = blockIdx.x * waves + wv;
+  float xn[3];
+  // ws: this launch also writes the element stiffness from both properties: the other property and the element length
+  // travel with the coordinates, one round ahead (loaded where they are used they cost a global round trip per round)
+  const pf_net onet = P.net[1 - which];
+  const float* __restrict__ oprop = which == 0 ? P.prop_a : P.prop_e;
+  float on = onet.scale, l0n = 1.0f;
+  if (n > 0) {
+    const int e0 = min(task * 64 + lane, n - 1);
+    load_x<IN>(xn, P, e0);
+    if (ws) {
+      if (onet.enabled) on = oprop[e0];
+      l0n = P.mesh.egeo[4 * (size_t)e0 + 3];
     }
-    if constexpr (LL >= 2) {
-      sfor<0, NR>([&](auto r) { constexpr int R = r; d[R] = acc[R] * A.t[LL - 2][R]; });
+  }
+  // the stop flag, one read per block (the bookkeeping that raises it may run beside this launch: a block whose waves
+  // disagreed would part ways before the lockstep barriers below)
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = P.state->done;
+  __syncthreads();
+  if (s_done || n <= 0) return;
+  const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
+  unsigned long long st0 = 0, sr0 = 0;
+  if (dbg & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+  for (int r = 0; r < rounds; ++r, task += per_round) {
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    const int e = task * 64 + lane;
+    float x0[3], x1[3];
+    sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
+    const float o = on, l0 = l0n;
+    if (r + 1 < rounds) {
+      const int en = min(e + per_round * 64, n - 1);
+      load_x<IN>(xn, P, en);
+      if (ws) {
+        if (onet.enabled) on = oprop[en];
+        l0n = P.mesh.egeo[4 * (size_t)en + 3];
+      }
     }
-  });
+    typename E::template TileAct<L, false> A0, A1;
+    float p0, p1;
+    E::template forward_tiles<L, IN, false>(smem, lane, x0, x1, A0, A1, p0, p1, dbg, grp);
+    const float z = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo;
+    if (e < n) {
+      const float v = (net.positive ? pf_softplus(z) : z) * net.scale;
+      out[e] = v;
+      // element stiffness for the node kernels: (young * area) / l0, nn_assembly.py:74 (2-D), :37 (1-D)
+      if (ws) P.elem_s[e] = (which == 0 ? v * o : o * v) / l0;
+    }
+    if (grp == 3) __builtin_amdgcn_s_barrier();
+  }
+  if ((dbg & 16) && lane == 0) {   // diagnostic build only: per-wave stamps into the (unused here) partial-sum workspace
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(P.partials) + (size_t)(blockIdx.x * waves + wv) * 4 + (size_t)which * 65536;
+    d[0] = sr0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = __builtin_amdgcn_s_memtime() - st0;
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    d[3] = ((unsigned long long)rounds << 48) | ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+  }
 }
 
 // GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the other net's
 // backward.  Partial gradient row of the block: the padded image of pf_common.h (what theta_stage1 sums).
-template <int L, int IN, bool GEA>
-__global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_problem P, int which, int hp, int dbg_arg) {
+template <int NR, int L, int IN, bool GEA>
+__global__ __launch_bounds__((Eng<NR>::template bw_threads<L, GEA>())) void k_net32_backward(pf_problem P, int which, int hp, int dbg_arg) {
+  using E = Eng<NR>;
+  constexpr int CONST_BYTES = E::CONST_BYTES, WAVE_SCRATCH = E::WAVE_SCRATCH, REGION = E::REGION, NPK = E::NPK;
+  constexpr bool COMPACT = E::COMPACT;
+  typedef typename E::WriteBase WriteBase;
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int DIM = IN - 1;
@@ -740,8 +751,8 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
   if (threadIdx.x < 32)
     if constexpr (COMPACT)
       *reinterpret_cast<unsigned short*>(cst + 192 + REGION + 64 * (threadIdx.x >> 2) + 8 * (threadIdx.x & 3) + 6) = BF ? 0x4500 : 0x6800;   // 2048.0
-  const unsigned char* rd = operand_base(scratch, lane, cst + 192);
-  const WriteBase wb = write_base(scratch, lane);
+  const unsigned char* rd = E::operand_base(scratch, lane, cst + 192);
+  const WriteBase wb = E::write_base(scratch, lane);
 
   const int stride = gridDim.x * waves * 64;
   int base = (blockIdx.x * waves + wv) * 64;
@@ -828,7 +839,7 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
     both_tiles(cur.x[1], xa0, xa1);
     both_tiles(cur.x[2], xb0, xb1);
     // ---- the two tiles ------------------------------------------------------------------------------------------
-    auto tile_backward = [&](const TileAct<L, true>& A, const float (&xt)[3], float gt) {
+    auto tile_backward = [&](const typename E::template TileAct<L, true>& A, const float (&xt)[3], float gt) {
       // inputs of the combined tile: (kl lam, kx x, kx y, 1) resp. (kl lam, kx x, 1, 0)
       unsigned xhi[NPK], xlo[NPK];
       sfor<2, NPK>([&](auto q) { constexpr int Q = q; xhi[Q] = 0u; xlo[Q] = 0u; });
@@ -836,21 +847,21 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
       split_pair(IN == 3 ? kx * xt[2] : 1.0f, IN == 3 ? 1.0f : 0.f, xhi[1], xlo[1]);
       // (before backward_tile: a'_L is dead there, ten registers less at the kernel's pressure peak)
       sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = fmaf(gt, A.aL[R], go[R]); });
-      if (!(dbg & 2)) backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, wb, rd, dbg);
+      if (!(dbg & 2)) E::template backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, wb, rd, dbg);
     };
-    if constexpr (bw_pair<L>()) {   // recompute both tiles together, then the two back-propagations (see bw_pair)
+    if constexpr (E::template bw_pair<L>()) {   // recompute both tiles together, then the two back-propagations (see bw_pair)
       const float x0[3] = {cur.x[0], xa0, xb0}, x1[3] = {cur.x[0], xa1, xb1};
-      TileAct<L, true> A0, A1;
+      typename E::template TileAct<L, true> A0, A1;
       float p0, p1;
-      forward_tiles<L, IN, true>(smem, lane, x0, x1, A0, A1, p0, p1);
+      E::template forward_tiles<L, IN, true>(smem, lane, x0, x1, A0, A1, p0, p1);
       tile_backward(A0, x0, g0);
       tile_backward(A1, x1, g1);
     } else {
       sfor<0, 2>([&](auto tt) {
         constexpr int TT = tt;
         const float xt[3] = {cur.x[0], TT ? xa1 : xa0, TT ? xb1 : xb0};
-        TileAct<L, true> A;
-        recompute_tile<L, IN>(smem, lane, xt, A);
+        typename E::template TileAct<L, true> A;
+        E::template recompute_tile<L, IN>(smem, lane, xt, A);
         tile_backward(A, xt, TT ? g1 : g0);
       });
     }
@@ -933,6 +944,7 @@ __global__ __launch_bounds__((bw_threads<L, GEA>())) void k_net32_backward(pf_pr
 
 template <int L, int IN>
 int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
+  constexpr int NR = PF_NR;
   const int n = p->mesh.n_elems;
   int nb = (n + FW_THREADS - 1) / FW_THREADS;
   static const int cap = getenv("PF_FWD32_BLOCKS") ? atoi(getenv("PF_FWD32_BLOCKS")) : 256;   // one block per CU
@@ -940,7 +952,7 @@ int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
   if (nb < 1) nb = 1;
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;   // timing experiments only
   const int ws = p->elem_s != nullptr ? 1 : 0;
-  hipLaunchKernelGGL((k_net32_forward<L, IN>), dim3(nb), dim3(FW_THREADS), pf_n32_bytes(L), s, *p, which, dbg, ws);
+  hipLaunchKernelGGL((k_net32_forward<NR, L, IN>), dim3(nb), dim3(FW_THREADS), pf_n32_bytes(L), s, *p, which, dbg, ws);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 
@@ -948,11 +960,13 @@ template <int L, int IN, bool GEA>
 int launch_bwd_t(const pf_problem* p, int which, hipStream_t s) {
   const int nb = pf_net_blocks(p);
   const int hp = ((p->net[which].width + 3) / 4) * 4;
-  constexpr int BW_THREADS = bw_threads<L, GEA>();
-  const size_t lds = ((pf_n32_bytes(L) + 255) & ~255) + CONST_BYTES + (size_t)(BW_THREADS / 64) * WAVE_SCRATCH;
-  static_assert(WAVE_SCRATCH >= 4096 + 512, "write-out staging must fit the wave scratch");
+  constexpr int NR = PF_NR;
+  using E = Eng<NR>;
+  constexpr int BW_THREADS = E::template bw_threads<L, GEA>();
+  const size_t lds = ((pf_n32_bytes(L) + 255) & ~255) + E::CONST_BYTES + (size_t)(BW_THREADS / 64) * E::WAVE_SCRATCH;
+  static_assert(E::WAVE_SCRATCH >= 4096 + 512, "write-out staging must fit the wave scratch");
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;   // timing experiments only
-  hipLaunchKernelGGL((k_net32_backward<L, IN, GEA>), dim3(nb), dim3(BW_THREADS), lds, s, *p, which, hp, dbg);
+  hipLaunchKernelGGL((k_net32_backward<NR, L, IN, GEA>), dim3(nb), dim3(BW_THREADS), lds, s, *p, which, hp, dbg);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>
