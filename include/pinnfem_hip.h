@@ -168,10 +168,12 @@ typedef struct pf_problem {
   /* MFMA32 engine, precision of the hidden-layer and gradient matrix products: PF_MLP_F32 (2-way split f16
    * operands, float32-grade; default) or PF_MLP_BF16 (plain bf16 operands, f32 accumulate) */
   int32_t mlp_dtype;
-  /* element stiffness s = (E*A)/l0 [n_elems] (2*n_elems with prop_double), written by the MFMA32 forward pass
-   * of the LAST evaluated net (same float operations as nn_assembly.py:74) and read by the node kernels instead of
-   * E, A and l0; NULL: the node kernels compute it from prop_e / prop_a / the constant properties */
-  float* elem_s;
+  /* per element, the three distinct entries of ke = s*pattern, s = (E*A)/l0: [n_elems][3] = s*c2, s*cs, s*s2 (2-D),
+   * [n_elems] = s (1-D); twice that with prop_double.  Written by the MFMA32 forward pass (the launch that evaluates the
+   * LAST enabled net, or the fused launch of both) with the float operations of nn_assembly.py:74, 84-94, and read by the
+   * node kernels instead of E, A and the geometry record (12 B per incidence instead of 20); NULL: the node kernels form
+   * the same numbers from prop_e / prop_a / the constant properties and mesh.egeo */
+  float* elem_k;
   /* per CSR entry of mesh.adj: the node at the OTHER end of that element ([adj_ptr[n_nodes]] int32).  With it the node
    * kernels fetch a neighbour's values one dependent load earlier (adj -> value instead of adj -> conn -> value) and
    * two incidences at a time; NULL: they go through mesh.conn. */

@@ -249,16 +249,17 @@ def ke_times(geo: Geometry, s: np.ndarray, ve: np.ndarray, fe_mode: str = "refer
     float32 cancellation of the reference order on long chains; opt-in extension)."""
     nd = geo.dofs.shape[1]
     if fe_mode == "delta":
+        # rows of ke = s*pattern (the reference's float32 product, nn_assembly.py:84-94) applied to d = v_j - v_i
         h = nd // 2
+        ke = (s[:, None, None] * geo.pattern).astype(f32)
         d = (ve[:, h:] - ve[:, :h]).astype(f32)
         q = np.zeros((len(s), h), dtype=f32)
         for a in range(h):
-            acc = (geo.pattern[:, a, 0] * d[:, 0]).astype(f32)
+            acc = (ke[:, a, 0] * d[:, 0]).astype(f32)
             for b in range(1, h):
-                acc = (acc + geo.pattern[:, a, b] * d[:, b]).astype(f32)
+                acc = (acc + ke[:, a, b] * d[:, b]).astype(f32)
             q[:, a] = acc
-        sq = (s[:, None] * q).astype(f32)
-        return np.concatenate([-sq, sq], axis=1).astype(f32)
+        return np.concatenate([-q, q], axis=1).astype(f32)
     ke = (s[:, None, None] * geo.pattern).astype(f32)
     out = np.zeros((len(s), nd), dtype=f32)
     for b in range(nd):                                    # 4-term dot, b ascending

@@ -83,7 +83,7 @@ class PfProblem(C.Structure):
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
         ("own_lo", C.c_int32), ("own_hi", C.c_int32), ("part_half", C.c_int32), ("prop_double", C.c_int32),
         ("net_op", C.c_void_p), ("op_off", C.c_int32 * 2), ("coord_exp", C.c_int32), ("mlp_dtype", C.c_int32),
-        ("elem_s", C.c_void_p), ("adj_other", C.c_void_p),
+        ("elem_k", C.c_void_p), ("adj_other", C.c_void_p),
     ]
 
 

@@ -109,11 +109,11 @@ static int check_problem(const pf_problem* p) {
   return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
 
 static int net_forward_impl(const pf_problem* p, int which, hipStream_t s);
-// write_s == 0: this forward is followed by the other net's, which writes the element stiffness (pf_problem.elem_s)
+// write_s == 0: this forward is followed by the other net's, which writes the stiffness records (pf_problem.elem_k)
 static int net_forward(const pf_problem* p, int which, hipStream_t s, int write_s = 1) {
-  if (write_s || !p->elem_s) return net_forward_impl(p, which, s);
+  if (write_s || !p->elem_k) return net_forward_impl(p, which, s);
   pf_problem q = *p;
-  q.elem_s = nullptr;
+  q.elem_k = nullptr;
   return net_forward_impl(&q, which, s);
 }
 static int net_forward_impl(const pf_problem* p, int which, hipStream_t s) {
@@ -121,6 +121,39 @@ static int net_forward_impl(const pf_problem* p, int which, hipStream_t s) {
   if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_forward_) }
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_forward_) }
   PF_WIDTH_SWITCH(pf_launch_net_forward_)
+}
+
+// both nets in ONE launch (pf_net32.hip: k_net32_forward2) where the engine has it: MFMA32, both nets enabled, same
+// number of hidden layers and inputs.  PF_FUSE_FWD=0: experiment knob (two launches, as before round 3).
+static bool can_fuse_forward(const pf_problem* p) {
+  static const int knob = getenv("PF_FUSE_FWD") ? atoi(getenv("PF_FUSE_FWD")) : 1;
+  return knob != 0 && p->wg_mode == PF_WG_MFMA32 && p->net[0].enabled && p->net[1].enabled &&
+         p->net[0].n_hidden == p->net[1].n_hidden && p->net[0].in_dim == p->net[1].in_dim;
+}
+#define PF_NR0_SWITCH(PREFIX)                                     \
+  switch (pf_net32_bucket(p->net[0].width)) {                     \
+    case 2: return PREFIX##2(p, s);                               \
+    case 4: return PREFIX##4(p, s);                               \
+    case 6: return PREFIX##6(p, s);                               \
+    case 8: return PREFIX##8(p, s);                               \
+    case 10: return PREFIX##10(p, s);                             \
+    case 12: return PREFIX##12(p, s);                             \
+    case 15: return PREFIX##15(p, s);                             \
+  }                                                               \
+  return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
+static int net_forward2(const pf_problem* p, hipStream_t s) {
+  if (p->mlp_dtype == PF_MLP_BF16) { PF_NR0_SWITCH(pf_launch_net32b_forward2_) }
+  PF_NR0_SWITCH(pf_launch_net32_forward2_)
+}
+// the forward pass of every enabled net: the properties and, with the MFMA32 engine, the stiffness records
+static int net_forward_all(const pf_problem* p, hipStream_t s) {
+  if (can_fuse_forward(p)) return net_forward2(p, s);
+  for (int k = 0; k < 2; ++k)
+    if (p->net[k].enabled) {
+      const int rc = net_forward(p, k, s, k == 1 || !p->net[1].enabled);
+      if (rc != PF_OK) return rc;
+    }
+  return PF_OK;
 }
 
 static int net_backward(const pf_problem* p, int which, hipStream_t s) {
@@ -307,9 +340,11 @@ static int enqueue_iteration(const pf_problem* p, int fuse_adam, int finalize_mo
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
 #define PF_MARK(k) do { if (ev && hipEventRecord(ev[k], s) != hipSuccess) return fail(PF_ERR_HIP, "hipEventRecord failed"); } while (0)
   PF_MARK(K_FWD_E);
-  if (p->net[0].enabled) PF_TRY(net_forward(p, 0, s, !p->net[1].enabled), "net_forward");
+  const bool fwd2 = can_fuse_forward(p);              // both nets in the first slot's launch; the second slot stays empty
+  if (fwd2) PF_TRY(net_forward2(p, s), "net_forward2");
+  else if (p->net[0].enabled) PF_TRY(net_forward(p, 0, s, !p->net[1].enabled), "net_forward");
   PF_MARK(K_FWD_A);
-  if (p->net[1].enabled) PF_TRY(net_forward(p, 1, s), "net_forward");
+  if (!fwd2 && p->net[1].enabled) PF_TRY(net_forward(p, 1, s), "net_forward");
   PF_MARK(K_RESIDUAL);
   PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
   const bool fuse_gea = any_net && fuse_gea_for(p);
@@ -425,14 +460,13 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     if (pingpong && (i & 1)) {
       q.prop_e += q.mesh.n_elems;
       q.prop_a += q.mesh.n_elems;
-      if (q.elem_s) q.elem_s += q.mesh.n_elems;
+      if (q.elem_k) q.elem_k += (size_t)q.mesh.n_elems * (q.mesh.dim == 2 ? 3 : 1);
     }
     q.part_half = i & 1;
     if (i > 0 && !pingpong && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
     // (the two forwards run one after the other: side by side on two branches they measured slower, 0.195 vs
-    // 0.190 ms per iteration with the f32 engine — the same issue pipe — and the second one writes elem_s from both)
-    for (int k = 0; k < 2; ++k)
-      if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
+    // 0.190 ms per iteration with the f32 engine — the same issue pipe — and the second one writes the stiffness records from both)
+    PF_TRY(net_forward_all(p, s), "net_forward");
     // residual(i) reads u(i) [gradu(i-1)]; its block 0 is finalize(i-1): behind stage 2 (this chain) and gradu(i-1)
     if (i > 0 && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
     if (fin_branch && !serial && i > 0) {
@@ -600,7 +634,7 @@ static pf_problem own_view(const pf_problem* p) {
     if (q.prop_e) q.prop_e += lo;
     if (q.prop_a) q.prop_a += lo;
     if (q.g_ea) q.g_ea += lo;
-    if (q.elem_s) q.elem_s += lo;
+    if (q.elem_k) q.elem_k += (size_t)lo * (p->mesh.dim == 2 ? 3 : 1);
     q.mesh.n_elems = p->own_hi - lo;
   }
   return q;
@@ -610,8 +644,7 @@ int pf_shard_forward(const pf_problem* p, void* stream) {
   int rc = check_shared(p);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  for (int k = 0; k < 2; ++k)
-    if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
+  PF_TRY(net_forward_all(p, s), "net_forward");
   return PF_OK;
 }
 
@@ -667,8 +700,7 @@ int pf_shard_graph_capture(const pf_problem* p, int iters, float* buf, float* u2
     const bool any_net = p->net[0].enabled || p->net[1].enabled;
     for (int i = 0; i < iters; ++i) {
       hipEvent_t* e = c.ev + 2 * i;
-      for (int k = 0; k < 2; ++k)
-        if (p->net[k].enabled) PF_TRY(net_forward(p, k, s, k == 1 || !p->net[1].enabled), "net_forward");
+      PF_TRY(net_forward_all(p, s), "net_forward");
       PF_TRY(pf_launch_node_residual(p, nullptr, 1, s), "node_residual");
       bool marked = false;                  // e[0]: the last reader of u (the element adjoint) is done
       auto mark = [&]() {

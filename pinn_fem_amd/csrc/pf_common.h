@@ -113,49 +113,77 @@ __device__ __forceinline__ ElemGeo load_geo(const float* __restrict__ egeo, int 
 }
 
 __device__ __forceinline__ float elem_stiffness(const pf_problem& P, int e, float l0) {
-  if (P.elem_s) return P.elem_s[e];     // written by the forward pass: the same (E * A) / l0
   const float E = P.net[0].enabled ? P.prop_e[e] : P.net[0].scale;
   const float A = P.net[1].enabled ? P.prop_a[e] : P.net[1].scale;
   return (E * A) / l0;  // nn_assembly.py:74 (2-D), :37 (1-D)
 }
 
-// rows `2*end`, `2*end+1` of (s*pattern) @ [v_i; v_j].
-// mode PF_FE_REFERENCE: the reference's operation order, a 4-term dot per row with b ascending
-//   (nn_assembly.py:96-100): s*c2*v_ix + s*cs*v_iy - s*c2*v_jx - s*cs*v_jy.  With |v| >> |v_j - v_i|
-//   (long chains) this cancels in float32 exactly like the reference does.
-// mode PF_FE_DELTA: the same product written on d = v_j - v_i (mathematically identical, no
-//   cancellation); not the reference's round-off, so it is opt-in.
+// The three distinct entries of an element's stiffness matrix ke = s * pattern (nn_assembly.py:74, 84-94): s*c2, s*cs,
+// s*s2 (1-D: s in c2).  The MFMA32 forward pass writes them per element (pf_problem.elem_k: 12 B, or 4 B in 1-D), so the
+// node kernels read ONE record per incidence instead of the geometry (16 B) and the stiffness (4 B); without the record
+// they are formed here by the same float operations, so both routes give the same bits.
+struct ElemK { float c2, cs, s2; };
+
 template <int DIM>
-__device__ __forceinline__ void ke_rows_times(const ElemGeo& g, float s, int end, const float* vi,
-                                              const float* vj, float* out, int mode) {
+__device__ __forceinline__ ElemK elem_k_from(const ElemGeo& g, float s) {
+  if (DIM == 2) return ElemK{s * g.c2, s * g.cs, s * g.s2};
+  return ElemK{s, 0.f, 0.f};
+}
+// unit stiffness: the pattern itself (1 * c2 == c2 exactly)
+template <int DIM>
+__device__ __forceinline__ ElemK elem_k_unit(const ElemGeo& g) {
+  if (DIM == 2) return ElemK{g.c2, g.cs, g.s2};
+  return ElemK{1.f, 0.f, 0.f};
+}
+template <int DIM>
+__device__ __forceinline__ ElemK load_k(const pf_problem& P, int e) {
+  if (P.elem_k) {
+    if (DIM == 2) {
+      const float* __restrict__ r = P.elem_k + 3 * (size_t)e;
+      return ElemK{r[0], r[1], r[2]};
+    }
+    return ElemK{P.elem_k[e], 0.f, 0.f};
+  }
+  const ElemGeo g = load_geo(P.mesh.egeo, e);
+  return elem_k_from<DIM>(g, elem_stiffness(P, e, g.l0));
+}
+
+// rows `2*end`, `2*end+1` of ke @ [v_i; v_j], ke = s*pattern given by its entries k.
+// mode PF_FE_REFERENCE: the reference's operation order, a 4-term dot per row with b ascending
+//   (nn_assembly.py:96-100): (s*c2)*v_ix + (s*cs)*v_iy - (s*c2)*v_jx - (s*cs)*v_jy.  With |v| >> |v_j - v_i|
+//   (long chains) this cancels in float32 exactly like the reference does.
+// mode PF_FE_DELTA: the same rows applied to d = v_j - v_i (mathematically identical, no cancellation);
+//   not the reference's round-off, so it is opt-in.
+template <int DIM>
+__device__ __forceinline__ void ke_rows_times(const ElemK& k, int end, const float* vi, const float* vj, float* out,
+                                              int mode) {
   const float sg = end ? -1.f : 1.f;  // rows 2,3 are the exactly negated rows 0,1
   if (DIM == 2) {
     if (mode == PF_FE_DELTA) {
       const float d0 = vj[0] - vi[0], d1 = vj[1] - vi[1];
-      const float q0 = fmaf(g.cs, d1, g.c2 * d0), q1 = fmaf(g.s2, d1, g.cs * d0);
-      out[0] = (-(sg * s)) * q0;
-      out[1] = (-(sg * s)) * q1;
+      const float q0 = fmaf(k.cs, d1, k.c2 * d0), q1 = fmaf(k.s2, d1, k.cs * d0);
+      out[0] = -sg * q0;
+      out[1] = -sg * q1;
       return;
     }
-    const float k_c2 = s * g.c2, k_cs = s * g.cs, k_s2 = s * g.s2;
     // row 0: [ c2, cs, -c2, -cs ]   row 1: [ cs, s2, -cs, -s2 ]
-    float r0 = (sg * k_c2) * vi[0];
-    r0 = fmaf(sg * k_cs, vi[1], r0);
-    r0 = fmaf(-(sg * k_c2), vj[0], r0);
-    r0 = fmaf(-(sg * k_cs), vj[1], r0);
-    float r1 = (sg * k_cs) * vi[0];
-    r1 = fmaf(sg * k_s2, vi[1], r1);
-    r1 = fmaf(-(sg * k_cs), vj[0], r1);
-    r1 = fmaf(-(sg * k_s2), vj[1], r1);
+    float r0 = (sg * k.c2) * vi[0];
+    r0 = fmaf(sg * k.cs, vi[1], r0);
+    r0 = fmaf(-(sg * k.c2), vj[0], r0);
+    r0 = fmaf(-(sg * k.cs), vj[1], r0);
+    float r1 = (sg * k.cs) * vi[0];
+    r1 = fmaf(sg * k.s2, vi[1], r1);
+    r1 = fmaf(-(sg * k.cs), vj[0], r1);
+    r1 = fmaf(-(sg * k.s2), vj[1], r1);
     out[0] = r0;
     out[1] = r1;
   } else {
     if (mode == PF_FE_DELTA) {
-      out[0] = (-(sg * s)) * (vj[0] - vi[0]);
+      out[0] = (-(sg * k.c2)) * (vj[0] - vi[0]);
       return;
     }
-    float r0 = (sg * s) * vi[0];  // [[1,-1],[-1,1]]
-    r0 = fmaf(-(sg * s), vj[0], r0);
+    float r0 = (sg * k.c2) * vi[0];  // [[1,-1],[-1,1]]
+    r0 = fmaf(-(sg * k.c2), vj[0], r0);
     out[0] = r0;
   }
 }
@@ -184,8 +212,9 @@ __device__ __forceinline__ float pf_elem_gea(const pf_problem& P, int e) {
   load_vec<DIM>(P.g_f, nn.x, gi);
   load_vec<DIM>(P.g_f, nn.y, gj);
   // (pattern @ u_e): rows 0,1 (end 0) and rows 2,3 (end 1) with unit stiffness
-  ke_rows_times<DIM>(g, 1.f, 0, ui, uj, pu0, P.fe_mode);
-  ke_rows_times<DIM>(g, 1.f, 1, ui, uj, pu1, P.fe_mode);
+  const ElemK k1 = elem_k_unit<DIM>(g);
+  ke_rows_times<DIM>(k1, 0, ui, uj, pu0, P.fe_mode);
+  ke_rows_times<DIM>(k1, 1, ui, uj, pu1, P.fe_mode);
   float gs = 0.f;
 #pragma unroll
   for (int c = 0; c < DIM; ++c) gs = fmaf(gi[c], pu0[c], gs);
@@ -261,7 +290,9 @@ PF_DECL_NET_LAUNCHERS(32)
   int pf_launch_net32_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s);  \
   int pf_launch_net32b_forward_##NRB(const pf_problem* p, int which, hipStream_t s);      \
   int pf_launch_net32b_backward_##NRB(const pf_problem* p, int which, hipStream_t s);     \
-  int pf_launch_net32b_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s);
+  int pf_launch_net32b_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s); \
+  int pf_launch_net32_forward2_##NRB(const pf_problem* p, hipStream_t s);                 \
+  int pf_launch_net32b_forward2_##NRB(const pf_problem* p, hipStream_t s);
 PF_DECL_NET32_LAUNCHERS(2)
 PF_DECL_NET32_LAUNCHERS(4)
 PF_DECL_NET32_LAUNCHERS(6)

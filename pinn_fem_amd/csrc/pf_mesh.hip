@@ -47,20 +47,19 @@ __device__ __forceinline__ void gather_kv(const pf_problem& P, const float* __re
       const int code0 = M.adj[idx], oth0 = P.adj_other[idx];
       const int code1 = two ? M.adj[idx + 1] : code0, oth1 = two ? P.adj_other[idx + 1] : oth0;
       const int e0 = code0 >> 1, e1 = code1 >> 1;
-      const ElemGeo g0 = load_geo(M.egeo, e0), g1 = load_geo(M.egeo, e1);
-      const float s0 = elem_stiffness(P, e0, g0.l0), s1 = elem_stiffness(P, e1, g1.l0);
+      const ElemK k0 = load_k<DIM>(P, e0), k1 = load_k<DIM>(P, e1);
       float vo0[2], vo1[2], fe[2];
       load_vec<DIM>(v, oth0, vo0);
       load_vec<DIM>(v, oth1, vo1);
       if (!(own_only && (e0 < P.own_lo || e0 >= P.own_hi))) {
         const int end = code0 & 1;
-        ke_rows_times<DIM>(g0, s0, end, end ? vo0 : vs, end ? vs : vo0, fe, P.fe_mode);
+        ke_rows_times<DIM>(k0, end, end ? vo0 : vs, end ? vs : vo0, fe, P.fe_mode);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) acc[c] += fe[c];
       }
       if (two && !(own_only && (e1 < P.own_lo || e1 >= P.own_hi))) {
         const int end = code1 & 1;
-        ke_rows_times<DIM>(g1, s1, end, end ? vo1 : vs, end ? vs : vo1, fe, P.fe_mode);
+        ke_rows_times<DIM>(k1, end, end ? vo1 : vs, end ? vs : vo1, fe, P.fe_mode);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) acc[c] += fe[c];
       }
@@ -72,12 +71,11 @@ __device__ __forceinline__ void gather_kv(const pf_problem& P, const float* __re
     const int e = code >> 1, end = code & 1;
     if (own_only && (e < P.own_lo || e >= P.own_hi)) continue;
     const int2 nn = reinterpret_cast<const int2*>(M.conn)[e];
-    const ElemGeo g = load_geo(M.egeo, e);
-    const float s = elem_stiffness(P, e, g.l0);
+    const ElemK k = load_k<DIM>(P, e);
     float vi[2], vj[2], fe[2];
     load_vec<DIM>(v, nn.x, vi);
     load_vec<DIM>(v, nn.y, vj);
-    ke_rows_times<DIM>(g, s, end, vi, vj, fe, P.fe_mode);
+    ke_rows_times<DIM>(k, end, vi, vj, fe, P.fe_mode);
 #pragma unroll
     for (int c = 0; c < DIM; ++c) acc[c] += fe[c];
   }
@@ -612,10 +610,9 @@ __global__ void k_diag_k(pf_problem P, float* diag) {
   float d[2] = {0.f, 0.f};
   for (int idx = M.adj_ptr[node]; idx < M.adj_ptr[node + 1]; ++idx) {
     const int e = M.adj[idx] >> 1;
-    const ElemGeo g = load_geo(M.egeo, e);
-    const float s = elem_stiffness(P, e, g.l0);
-    if (DIM == 2) { d[0] += s * g.c2; d[1] += s * g.s2; }
-    else d[0] += s;
+    const ElemK k = load_k<DIM>(P, e);
+    if (DIM == 2) { d[0] += k.c2; d[1] += k.s2; }
+    else d[0] += k.c2;
   }
 #pragma unroll
   for (int c = 0; c < DIM; ++c) diag[node * DIM + c] = d[c];
@@ -630,8 +627,7 @@ __global__ void k_dense_k(pf_problem P, float* K) {
   const int nd = 2 * DIM;
   for (int e = 0; e < M.n_elems; ++e) {
     const int2 nn = reinterpret_cast<const int2*>(M.conn)[e];
-    const ElemGeo g = load_geo(M.egeo, e);
-    const float s = elem_stiffness(P, e, g.l0);
+    const ElemK k = load_k<DIM>(P, e);
     const int t = threadIdx.x;
     if (t < nd * nd) {
       const int a = t / nd, b = t % nd;
@@ -640,14 +636,14 @@ __global__ void k_dense_k(pf_problem P, float* K) {
       if (DIM == 2) {
         da = (a < 2 ? nn.x : nn.y) * 2 + (a & 1);
         db = (b < 2 ? nn.x : nn.y) * 2 + (b & 1);
-        const float base = ((a & 1) == 0 && (b & 1) == 0) ? g.c2 : (((a & 1) && (b & 1)) ? g.s2 : g.cs);
-        pat = ((a < 2) == (b < 2)) ? base : -base;
+        const float base = ((a & 1) == 0 && (b & 1) == 0) ? k.c2 : (((a & 1) && (b & 1)) ? k.s2 : k.cs);
+        pat = ((a < 2) == (b < 2)) ? base : -base;     // entry of ke = s*pattern (the product is already in k)
       } else {
         da = a == 0 ? nn.x : nn.y;
         db = b == 0 ? nn.x : nn.y;
-        pat = a == b ? 1.f : -1.f;
+        pat = a == b ? k.c2 : -k.c2;
       }
-      K[(size_t)da * M.n_dofs + db] += s * pat;
+      K[(size_t)da * M.n_dofs + db] += pat;
     }
     __syncthreads();
   }

@@ -220,14 +220,28 @@ __device__ __forceinline__ void task_fetch_b(TaskIn<IN - 1>& t, const pf_problem
 template <int DIM>
 __device__ __forceinline__ float task_gea(const TaskIn<DIM>& t, int fe_mode) {
   float pu0[2], pu1[2];
-  ke_rows_times<DIM>(t.g, 1.f, 0, t.ui, t.uj, pu0, fe_mode);
-  ke_rows_times<DIM>(t.g, 1.f, 1, t.ui, t.uj, pu1, fe_mode);
+  const ElemK k1 = elem_k_unit<DIM>(t.g);
+  ke_rows_times<DIM>(k1, 0, t.ui, t.uj, pu0, fe_mode);
+  ke_rows_times<DIM>(k1, 1, t.ui, t.uj, pu1, fe_mode);
   float gs = 0.f;
 #pragma unroll
   for (int c = 0; c < DIM; ++c) gs = fmaf(t.gi[c], pu0[c], gs);
 #pragma unroll
   for (int c = 0; c < DIM; ++c) gs = fmaf(t.gj[c], pu1[c], gs);
   return gs / t.g.l0;
+}
+
+// entries of ke = s*pattern of one element -> the record the node kernels read (pf_common.h: ElemK, load_k)
+template <int DIM>
+__device__ __forceinline__ void store_k(float* __restrict__ elem_k, int e, const ElemGeo& g, float s) {
+  if (DIM == 2) {
+    float* __restrict__ r = elem_k + 3 * (size_t)e;
+    r[0] = s * g.c2;
+    r[1] = s * g.cs;
+    r[2] = s * g.s2;
+  } else {
+    elem_k[e] = s;
+  }
 }
 
 // ---- everything that depends on the register bucket NR (registers per lane that carry real units: nets of width <= 2 NR)
@@ -664,17 +678,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
   const int rounds = (ntasks + per_round - 1) / per_round;        // block-uniform trip count: equal barrier counts
   int task = blockIdx.x * waves + wv;
   float xn[3];
-  // ws: this launch also writes the element stiffness from both properties: the other property and the element length
+  // ws: this launch also writes the stiffness records from both properties: the other property and the element geometry
   // travel with the coordinates, one round ahead (loaded where they are used they cost a global round trip per round)
   const pf_net onet = P.net[1 - which];
   const float* __restrict__ oprop = which == 0 ? P.prop_a : P.prop_e;
-  float on = onet.scale, l0n = 1.0f;
+  float on = onet.scale;
+  ElemGeo gn = ElemGeo{0.f, 0.f, 0.f, 1.f};
   if (n > 0) {
     const int e0 = min(task * 64 + lane, n - 1);
     load_x<IN>(xn, P, e0);
     if (ws) {
       if (onet.enabled) on = oprop[e0];
-      l0n = P.mesh.egeo[4 * (size_t)e0 + 3];
+      gn = load_geo(P.mesh.egeo, e0);
     }
   }
   // the stop flag, one read per block (the bookkeeping that raises it may run beside this launch: a block whose waves
@@ -691,13 +706,14 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
     const int e = task * 64 + lane;
     float x0[3], x1[3];
     sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
-    const float o = on, l0 = l0n;
+    const float o = on;
+    const ElemGeo g = gn;
     if (r + 1 < rounds) {
       const int en = min(e + per_round * 64, n - 1);
       load_x<IN>(xn, P, en);
       if (ws) {
         if (onet.enabled) on = oprop[en];
-        l0n = P.mesh.egeo[4 * (size_t)en + 3];
+        gn = load_geo(P.mesh.egeo, en);
       }
     }
     typename E::template TileAct<L, false> A0, A1;
@@ -707,8 +723,9 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
     if (e < n) {
       const float v = (net.positive ? pf_softplus(z) : z) * net.scale;
       out[e] = v;
-      // element stiffness for the node kernels: (young * area) / l0, nn_assembly.py:74 (2-D), :37 (1-D)
-      if (ws) P.elem_s[e] = (which == 0 ? v * o : o * v) / l0;
+      // stiffness record for the node kernels: s = (young * area) / l0, nn_assembly.py:74 (2-D), :37 (1-D), times the
+      // pattern entries (:84-94)
+      if (ws) store_k<IN - 1>(P.elem_k, e, g, (which == 0 ? v * o : o * v) / g.l0);
     }
     if (grp == 3) __builtin_amdgcn_s_barrier();
   }
@@ -718,6 +735,83 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
     unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     d[3] = ((unsigned long long)rounds << 48) | ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+  }
+}
+
+// ---- fused forward of BOTH nets (young and area) --------------------------------------------------------------------
+// One launch instead of two: the wave's 64 elements go through the E net and then the A net (both operand images sit in
+// LDS), the coordinates are loaded and exchanged between the half-waves once, and the stiffness record is formed from
+// both values in registers — no second launch floor, no second prologue, no round trip of the first property through
+// memory.  Same block shape and lockstep scheme as k_net32_forward; the four wave groups pass their ONE barrier per task
+// at: task start | after the E net's first activation | after the A net's hidden layers | task end.
+// s2: this launch is also the THETA UPDATE of the previous iteration (the iteration graph): every block sums the
+// second-level partial rows, applies Adam to its own copy of theta and builds both operand images straight into its LDS
+// (all blocks compute the same bits); block 0 stores theta, the moments, the images and the theta-norm monitor — see
+// fwd2_theta_prologue.
+template <int NRE, int NRA, int L, int IN>
+__global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg) {
+  using EE = Eng<NRE>;
+  using EA = Eng<NRA>;
+  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int IMG = pf_n32_bytes(L), IMGP = (IMG + 255) & ~255;
+  const unsigned char* __restrict__ img_e = smem;
+  const unsigned char* __restrict__ img_a = smem + IMGP;
+  const pf_net net_e = P.net[0], net_a = P.net[1];
+  copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[0]), IMG);
+  copy_image(smem + IMGP, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[1]), IMG);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
+  const int grp = (dbg & 32) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  const int n = P.mesh.n_elems;
+  const int ntasks = (n + 63) >> 6;
+  const int per_round = gridDim.x * waves;
+  const int rounds = (ntasks + per_round - 1) / per_round;
+  int task = blockIdx.x * waves + wv;
+  float xn[3];
+  ElemGeo gn = ElemGeo{0.f, 0.f, 0.f, 1.f};
+  if (n > 0) {
+    const int e0 = min(task * 64 + lane, n - 1);
+    load_x<IN>(xn, P, e0);
+    gn = load_geo(P.mesh.egeo, e0);
+  }
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = P.state->done;
+  __syncthreads();
+  if (s_done || n <= 0) return;
+  const float bo_e = reinterpret_cast<const float*>(img_e + pf_n32_off_bo())[0];
+  const float bo_a = reinterpret_cast<const float*>(img_a + pf_n32_off_bo())[0];
+  for (int r = 0; r < rounds; ++r, task += per_round) {
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    const int e = task * 64 + lane;
+    float x0[3], x1[3];
+    sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
+    const ElemGeo g = gn;
+    if (r + 1 < rounds) {
+      const int en = min(e + per_round * 64, n - 1);
+      load_x<IN>(xn, P, en);
+      gn = load_geo(P.mesh.egeo, en);
+    }
+    float ze, za;
+    {
+      typename EE::template TileAct<L, false> A0, A1;
+      float p0, p1;
+      EE::template forward_tiles<L, IN, false>(img_e, lane, x0, x1, A0, A1, p0, p1, dbg, grp == 1 ? 1 : -1);
+      ze = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo_e;
+    }
+    {
+      typename EA::template TileAct<L, false> A0, A1;
+      float p0, p1;
+      EA::template forward_tiles<L, IN, false>(img_a, lane, x0, x1, A0, A1, p0, p1, dbg, grp == 2 ? 2 : -1);
+      za = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo_a;
+    }
+    if (e < n) {
+      const float ve = (net_e.positive ? pf_softplus(ze) : ze) * net_e.scale;
+      const float va = (net_a.positive ? pf_softplus(za) : za) * net_a.scale;
+      P.prop_e[e] = ve;
+      P.prop_a[e] = va;
+      if (P.elem_k) store_k<IN - 1>(P.elem_k, e, g, (ve * va) / g.l0);    // (young * area) / l0, nn_assembly.py:74, :37
+    }
+    if (grp == 3) __builtin_amdgcn_s_barrier();
   }
 }
 
@@ -951,7 +1045,7 @@ int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;   // timing experiments only
-  const int ws = p->elem_s != nullptr ? 1 : 0;
+  const int ws = p->elem_k != nullptr ? 1 : 0;
   hipLaunchKernelGGL((k_net32_forward<NR, L, IN>), dim3(nb), dim3(FW_THREADS), pf_n32_bytes(L), s, *p, which, dbg, ws);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
@@ -974,8 +1068,50 @@ int launch_bwd(const pf_problem* p, int which, hipStream_t s) { return launch_bw
 template <int L, int IN>
 int launch_bwd_gea(const pf_problem* p, int which, hipStream_t s) { return launch_bwd_t<L, IN, true>(p, which, s); }
 
+// fused forward of both nets: the E net's bucket is this translation unit's PF_NR, the A net's bucket is dispatched here
+template <int NRA, int L, int IN>
+int launch_fwd2_t(const pf_problem* p, hipStream_t s) {
+  constexpr int NRE = PF_NR;
+  const int n = p->mesh.n_elems;
+  int nb = (n + FW_THREADS - 1) / FW_THREADS;
+  static const int cap = getenv("PF_FWD32_BLOCKS") ? atoi(getenv("PF_FWD32_BLOCKS")) : 256;   // one block per CU
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;
+  const size_t lds = 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255);
+  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+template <int L, int IN>
+int launch_fwd2(const pf_problem* p, hipStream_t s) {
+  switch (pf_net32_bucket(p->net[1].width)) {
+    case 2: return launch_fwd2_t<2, L, IN>(p, s);
+    case 4: return launch_fwd2_t<4, L, IN>(p, s);
+    case 6: return launch_fwd2_t<6, L, IN>(p, s);
+    case 8: return launch_fwd2_t<8, L, IN>(p, s);
+    case 10: return launch_fwd2_t<10, L, IN>(p, s);
+    case 12: return launch_fwd2_t<12, L, IN>(p, s);
+    case 15: return launch_fwd2_t<15, L, IN>(p, s);
+  }
+  pf_set_error("MFMA32 engine: area net width outside 1..30");
+  return PF_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
+#if PF_PREC == 1
+#define PF_N32_SYM(kind) PF_CAT(PF_CAT(pf_launch_net32b_, kind), PF_NR)
+#else
+#define PF_N32_SYM(kind) PF_CAT(PF_CAT(pf_launch_net32_, kind), PF_NR)
+#endif
+
+// PF_N32_PART 0: the single-net kernels of this bucket; 1: the fused two-net kernels whose E net is of this bucket
+// (separate translation units: the build compiles them side by side)
+#ifndef PF_N32_PART
+#define PF_N32_PART 0
+#endif
+
+#if PF_N32_PART == 0
 #define PF_DISPATCH(FN)                                             \
   const pf_net& net = p->net[which];                                \
   const int L = net.n_hidden, IN = net.in_dim;                      \
@@ -991,11 +1127,6 @@ int launch_bwd_gea(const pf_problem* p, int which, hipStream_t s) { return launc
   pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)"); \
   return PF_ERR_UNSUPPORTED;
 
-#if PF_PREC == 1
-#define PF_N32_SYM(kind) PF_CAT(PF_CAT(pf_launch_net32b_, kind), PF_NR)
-#else
-#define PF_N32_SYM(kind) PF_CAT(PF_CAT(pf_launch_net32_, kind), PF_NR)
-#endif
 int PF_N32_SYM(forward_)(const pf_problem* p, int which, hipStream_t s) {
   PF_DISPATCH(launch_fwd)
 }
@@ -1005,3 +1136,20 @@ int PF_N32_SYM(backward_)(const pf_problem* p, int which, hipStream_t s) {
 int PF_N32_SYM(backward_gea_)(const pf_problem* p, int which, hipStream_t s) {
   PF_DISPATCH(launch_bwd_gea)
 }
+#else
+// both nets enabled, same number of hidden layers and the same inputs (pf_api.hip checks): young net of THIS bucket
+int PF_N32_SYM(forward2_)(const pf_problem* p, hipStream_t s) {
+  const int L = p->net[0].n_hidden, IN = p->net[0].in_dim;
+  if (IN == 3) {
+    if (L == 1) return launch_fwd2<1, 3>(p, s);
+    if (L == 2) return launch_fwd2<2, 3>(p, s);
+    if (L == 3) return launch_fwd2<3, 3>(p, s);
+  } else if (IN == 2) {
+    if (L == 1) return launch_fwd2<1, 2>(p, s);
+    if (L == 2) return launch_fwd2<2, 2>(p, s);
+    if (L == 3) return launch_fwd2<3, 2>(p, s);
+  }
+  pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)");
+  return PF_ERR_UNSUPPORTED;
+}
+#endif

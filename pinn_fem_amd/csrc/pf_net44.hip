@@ -292,8 +292,9 @@ __device__ __forceinline__ void task_fetch_b(TaskIn<IN - 1>& t, const pf_problem
 template <int DIM>
 __device__ __forceinline__ float task_gea(const TaskIn<DIM>& t, int fe_mode) {
   float pu0[2], pu1[2];
-  ke_rows_times<DIM>(t.g, 1.f, 0, t.ui, t.uj, pu0, fe_mode);
-  ke_rows_times<DIM>(t.g, 1.f, 1, t.ui, t.uj, pu1, fe_mode);
+  const ElemK k1 = elem_k_unit<DIM>(t.g);
+  ke_rows_times<DIM>(k1, 0, t.ui, t.uj, pu0, fe_mode);
+  ke_rows_times<DIM>(k1, 1, t.ui, t.uj, pu1, fe_mode);
   float gs = 0.f;
 #pragma unroll
   for (int c = 0; c < DIM; ++c) gs = fmaf(t.gi[c], pu0[c], gs);

@@ -160,8 +160,9 @@ class HipEngine:
         # uses the first
         self.prop_e = torch.zeros(2 * ne, **f32)
         self.prop_a = torch.zeros(2 * ne, **f32)
-        # element stiffness (E*A)/l0 written by the MFMA32 forward pass for the node kernels (two halves, like the properties)
-        self.elem_s = (torch.zeros(2 * ne, **f32)
+        # entries of ke = s*pattern per element (s*c2, s*cs, s*s2; 1-D: s), written by the MFMA32 forward pass for the node
+        # kernels (two halves, like the properties)
+        self.elem_k = (torch.zeros(2 * ne * (3 if hp.dim == 2 else 1), **f32)
                        if self.wg_mode == _capi.PF_WG_MFMA32 and any(sp.enabled for sp in self.specs) else None)
         self.g_f = torch.zeros(nd, **f32)
         self.g_ea = torch.zeros(ne, **f32)
@@ -249,7 +250,7 @@ class HipEngine:
         P.op_off[0], P.op_off[1] = self._op_off
         P.coord_exp = self.coord_exp
         P.mlp_dtype = _capi.PF_MLP_BF16 if self.mlp_dtype == "bf16" else _capi.PF_MLP_F32
-        P.elem_s = self.elem_s.data_ptr() if self.elem_s is not None else None
+        P.elem_k = self.elem_k.data_ptr() if self.elem_k is not None else None
         P.adj_other = self.adj_other.data_ptr()
         self._configured = True
 
