@@ -11,11 +11,12 @@ from pinn_fem_amd.engine import HipEngine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 fe = int(sys.argv[2]) if len(sys.argv) > 2 else 1        # element-force formulation: 0 reference, 1 delta
+hh = float(sys.argv[3]) if len(sys.argv) > 3 else 3.0 / n    # element length (1.0: layer-1 units saturate at the far end)
 names = ["E.W1", "E.b1", "E.W2", "E.b2", "E.Wo", "E.bo", "A.W1", "A.b1", "A.W2", "A.b2", "A.Wo", "A.bo"]
 for span in (0.0, 4.0, 10.0):
     for direction in ("rising", "falling"):
         for wg, blocks in ((3, 2), (3, 1024), (2, 1024)):
-            model, pb, mv, md = _chain_model(n, h=1.0)
+            model, pb, mv, md = _chain_model(n, h=hh)
             eng = HipEngine(model, mv, md, n_part_blocks=blocks, wg_mode=wg, fe_mode=fe)
             e = np.arange(n, dtype=np.float64)
             expo = -span + 2 * span * e / (n - 1)
