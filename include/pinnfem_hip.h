@@ -93,7 +93,8 @@ typedef struct pf_state {
   int32_t iter;        /* completed iterations (= Adam step count) */
   int32_t done;        /* 1 once the stop test fired (solver.py:341-355); later launches no-op */
   int32_t converged;   /* same as done (kept separate for max_iterations exits) */
-  int32_t _pad;
+  int32_t theta_half;  /* which half holds the current theta / Adam moments: 0 = p->theta, m_t, v_t; 1 = p->theta_alt
+                          (only the iteration graph ever leaves it at 1, and only between its own kernels) */
   /* Adam scalars for the NEXT step, computed in double like torch does on the host */
   float step_size_u, step_size_t, bc2_sqrt, _pad2;
   /* last iteration's monitors (solver.py:304-320) */
@@ -174,6 +175,14 @@ typedef struct pf_problem {
    * node kernels instead of E, A and the geometry record (12 B per incidence instead of 20); NULL: the node kernels form
    * the same numbers from prop_e / prop_a / the constant properties and mesh.egeo */
   float* elem_k;
+  /* second half of the parameter state: [3][n_theta] floats = theta | m_t | v_t, or NULL.  With it the iteration graph
+   * folds the parameter update of iteration t (sum of the second-level partial rows, optimizer_theta.step(),
+   * solver.py:293-294, operand images) into the prologue of the forward launch of iteration t+1: EVERY block of that
+   * launch computes the update for itself from the half the previous update wrote and builds the operand images in its
+   * own LDS; block 0 stores the new state into the OTHER half (nobody reads that one during the launch) and flips
+   * state->theta_half.  The single-block update launch and one kernel boundary leave the critical path; a replay ends
+   * with a stand-alone update that brings the state back to half 0. */
+  float* theta_alt;
   /* per CSR entry of mesh.adj: the node at the OTHER end of that element ([adj_ptr[n_nodes]] int32).  With it the node
    * kernels fetch a neighbour's values one dependent load earlier (adj -> value instead of adj -> conn -> value) and
    * two incidences at a time; NULL: they go through mesh.conn. */

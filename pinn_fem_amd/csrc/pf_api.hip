@@ -108,17 +108,30 @@ static int check_problem(const pf_problem* p) {
   }                                                               \
   return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
 
-static int net_forward_impl(const pf_problem* p, int which, hipStream_t s);
-// write_s == 0: this forward is followed by the other net's, which writes the stiffness records (pf_problem.elem_k)
-static int net_forward(const pf_problem* p, int which, hipStream_t s, int write_s = 1) {
-  if (write_s || !p->elem_k) return net_forward_impl(p, which, s);
+static int net_forward_impl(const pf_problem* p, int which, hipStream_t s, int s2_half);
+// write_s == 0: this forward is followed by the other net's, which writes the stiffness records (pf_problem.elem_k).
+// s2_half >= 0 (MFMA32 engine): the launch first runs the previous iteration's parameter update from that state half.
+static int net_forward(const pf_problem* p, int which, hipStream_t s, int write_s = 1, int s2_half = -1) {
+  if (write_s || !p->elem_k) return net_forward_impl(p, which, s, s2_half);
   pf_problem q = *p;
   q.elem_k = nullptr;
-  return net_forward_impl(&q, which, s);
+  return net_forward_impl(&q, which, s, s2_half);
 }
-static int net_forward_impl(const pf_problem* p, int which, hipStream_t s) {
-  if (p->wg_mode == PF_WG_MFMA32 && p->mlp_dtype == PF_MLP_BF16) { PF_NR_SWITCH(pf_launch_net32b_forward_) }
-  if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH(pf_launch_net32_forward_) }
+#define PF_NR_SWITCH_FWD(PREFIX)                                  \
+  switch (pf_net32_bucket(p->net[which].width)) {                 \
+    case 2: return PREFIX##2(p, which, s, s2_half);               \
+    case 4: return PREFIX##4(p, which, s, s2_half);               \
+    case 6: return PREFIX##6(p, which, s, s2_half);               \
+    case 8: return PREFIX##8(p, which, s, s2_half);               \
+    case 10: return PREFIX##10(p, which, s, s2_half);             \
+    case 12: return PREFIX##12(p, which, s, s2_half);             \
+    case 15: return PREFIX##15(p, which, s, s2_half);             \
+  }                                                               \
+  return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
+static int net_forward_impl(const pf_problem* p, int which, hipStream_t s, int s2_half) {
+  if (p->wg_mode == PF_WG_MFMA32 && p->mlp_dtype == PF_MLP_BF16) { PF_NR_SWITCH_FWD(pf_launch_net32b_forward_) }
+  if (p->wg_mode == PF_WG_MFMA32) { PF_NR_SWITCH_FWD(pf_launch_net32_forward_) }
+  if (s2_half >= 0) return fail(PF_ERR_ARG, "the fused parameter update exists in the MFMA32 engine only");
   if (p->wg_mode == PF_WG_MFMA44) { PF_WIDTH_SWITCH(pf_launch_net44_forward_) }
   PF_WIDTH_SWITCH(pf_launch_net_forward_)
 }
@@ -132,28 +145,37 @@ static bool can_fuse_forward(const pf_problem* p) {
 }
 #define PF_NR0_SWITCH(PREFIX)                                     \
   switch (pf_net32_bucket(p->net[0].width)) {                     \
-    case 2: return PREFIX##2(p, s);                               \
-    case 4: return PREFIX##4(p, s);                               \
-    case 6: return PREFIX##6(p, s);                               \
-    case 8: return PREFIX##8(p, s);                               \
-    case 10: return PREFIX##10(p, s);                             \
-    case 12: return PREFIX##12(p, s);                             \
-    case 15: return PREFIX##15(p, s);                             \
+    case 2: return PREFIX##2(p, s, s2_half);                      \
+    case 4: return PREFIX##4(p, s, s2_half);                      \
+    case 6: return PREFIX##6(p, s, s2_half);                      \
+    case 8: return PREFIX##8(p, s, s2_half);                      \
+    case 10: return PREFIX##10(p, s, s2_half);                    \
+    case 12: return PREFIX##12(p, s, s2_half);                    \
+    case 15: return PREFIX##15(p, s, s2_half);                    \
   }                                                               \
   return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
-static int net_forward2(const pf_problem* p, hipStream_t s) {
+static int net_forward2(const pf_problem* p, hipStream_t s, int s2_half = -1) {
   if (p->mlp_dtype == PF_MLP_BF16) { PF_NR0_SWITCH(pf_launch_net32b_forward2_) }
   PF_NR0_SWITCH(pf_launch_net32_forward2_)
 }
-// the forward pass of every enabled net: the properties and, with the MFMA32 engine, the stiffness records
-static int net_forward_all(const pf_problem* p, hipStream_t s) {
-  if (can_fuse_forward(p)) return net_forward2(p, s);
+// the forward pass of every enabled net: the properties and, with the MFMA32 engine, the stiffness records.
+// s2_half >= 0: the FIRST launch also runs the parameter update of the previous iteration (can_fuse_theta_update)
+static int net_forward_all(const pf_problem* p, hipStream_t s, int s2_half = -1) {
+  if (can_fuse_forward(p)) return net_forward2(p, s, s2_half);
   for (int k = 0; k < 2; ++k)
     if (p->net[k].enabled) {
-      const int rc = net_forward(p, k, s, k == 1 || !p->net[1].enabled);
+      const int rc = net_forward(p, k, s, k == 1 || !p->net[1].enabled, s2_half);
       if (rc != PF_OK) return rc;
+      s2_half = -1;
     }
   return PF_OK;
+}
+// Can the iteration graph fold the parameter update of iteration t into the forward launch of t+1?  MFMA32 engine with
+// the second state half present; PF_FUSE_S2=0: experiment knob (stand-alone update launch every iteration).
+static bool can_fuse_theta_update(const pf_problem* p) {
+  static const int knob = getenv("PF_FUSE_S2") ? atoi(getenv("PF_FUSE_S2")) : 1;
+  return knob != 0 && p->wg_mode == PF_WG_MFMA32 && p->theta_alt != nullptr && p->n_theta_active > 0 &&
+         (p->net[0].enabled || p->net[1].enabled);
 }
 
 static int net_backward(const pf_problem* p, int which, hipStream_t s) {
@@ -390,14 +412,15 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
 
 // Iterations as a dependency graph instead of a chain (only meaningful while capturing a hipGraph).
 // What each kernel of iteration t really waits for:
-//   forward E, A        theta_pad(t)  [stage 2 of t-1];  nothing reads prop_e/prop_a any more  [gradu of t-1]
-//   node_residual       forwards, u(t) [gradu of t-1]; its block 0 = finalize(t-1): stage 2 of t-1, gradu of t-1, and the
+//   forward (E and A in one launch)   the second-level gradient rows of t-1 [theta stage 1 of t-1]: its prologue IS the
+//                       parameter update of t-1 (every block for itself; MFMA32 engine);  nothing reads the properties
+//                       or stiffness records of the other half any more  [gradu of t-1]
+//   node_residual       forward, u(t) [gradu of t-1]; its block 0 = finalize(t-1): the update of t-1, gradu of t-1, and the
 //                       OTHER half of the residual's partial sums (part_half)
 //   backward #1 (+gea)  g_f; it is the last reader of u(t)
-//   gradu + Adam(u)     g_f, the properties, backward #1 done; the Adam scalars                [finalize of t-1]
-//   backward #2, theta stage 1, stage 2 + Adam(theta)   in this order after backward #1
-//   finalize(t)         stage 2 and gradu of t: it runs inside node_residual(t+1) (PF_GRAPH_FIN=branch: as a node of its
-//                       own on a second side branch, the round-1 form)
+//   gradu + Adam(u)     g_f, the stiffness records, backward #1 done; the Adam scalars          [finalize of t-1]
+//   backward #2, theta stage 1   in this order after backward #1 (the last iteration of a replay: + the stand-alone update)
+//   finalize(t)         the update and gradu of t: it runs inside node_residual(t+1)
 // so gradu (HBM bound) runs on branch A beside backward #2 and the theta reduction (compute bound).  The stop flag
 // is read by every kernel at its start; a kernel of t+1 that misses a stop raised by finalize(t) only rewrites scratch
 // (properties, g_f, partial sums): everything that changes solver state (both Adam kernels, the next finalize)
@@ -430,9 +453,9 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     }
     return PF_OK;
   }
-  // serial: the same kernels as ONE chain on `s` (no side branch, no events): forwards, residual [+ finalize of the
-  // previous iteration in its block 0], backwards, theta stage 1 + 2, gradu — the bookkeeping costs no launch of its
-  // own there either (the eager sequence ends with a single-block kernel that does theta stage 2 AND the bookkeeping).
+  // serial: the same kernels as ONE chain on `s` (no side branch, no events): forward, residual [+ finalize of the
+  // previous iteration in its block 0], backwards, theta stage 1, gradu — neither the bookkeeping nor the parameter update
+  // costs a launch of its own there either.
   hipStream_t sa = serial ? s : c.a;
   auto ev_wait = [&](hipStream_t st, hipEvent_t e) { return serial || hipStreamWaitEvent(st, e, 0) == hipSuccess; };
   auto ev_rec = [&](hipEvent_t e, hipStream_t st) { return serial || hipEventRecord(e, st) == hipSuccess; };
@@ -447,7 +470,11 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   static const bool pp_knob = !(getenv("PF_GRAPH_PINGPONG") && atoi(getenv("PF_GRAPH_PINGPONG")) == 0);
   const bool pingpong = p->prop_double != 0 && pp_knob;
   const int tn_ready = p->wg_mode == PF_WG_MFMA32 ? 1 : 0;   // k_theta_stage2 leaves the theta-norm monitor in the state
-  static const bool fin_branch = getenv("PF_GRAPH_FIN") && !strcmp(getenv("PF_GRAPH_FIN"), "branch");   // experiment knob
+  // The parameter update of iteration i-1 (theta stage 2: second-level rows -> Adam -> operand images) runs in the
+  // PROLOGUE of iteration i's forward launch, by every block for itself (pf_net32.hip: fwd_theta_prologue); the state
+  // ping-pongs between its two halves so that block 0's stores never meet another block's loads.  Only the replay's
+  // last iteration keeps the stand-alone update, which also brings the state back to half 0.
+  const bool fuse_s2 = can_fuse_theta_update(p);
   for (int i = 0; i < iters; ++i) {
     hipEvent_t* e = c.ev + PF_CAP_EV * i;
     hipEvent_t* ep = c.ev + PF_CAP_EV * (i - 1);
@@ -464,22 +491,13 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     }
     q.part_half = i & 1;
     if (i > 0 && !pingpong && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
-    // (the two forwards run one after the other: side by side on two branches they measured slower, 0.195 vs
-    // 0.190 ms per iteration with the f32 engine — the same issue pipe — and the second one writes the stiffness records from both)
-    PF_TRY(net_forward_all(p, s), "net_forward");
-    // residual(i) reads u(i) [gradu(i-1)]; its block 0 is finalize(i-1): behind stage 2 (this chain) and gradu(i-1)
+    // (both nets in one launch where the engine has it; else one after the other: side by side on two branches they
+    // measured slower, the same issue pipe, and the second one writes the stiffness records from both)
+    PF_TRY(net_forward_all(p, s, fuse_s2 && i > 0 ? ((i - 1) & 1) : -1), "net_forward");
+    // residual(i) reads u(i) [gradu(i-1)]; its block 0 is finalize(i-1): behind the theta update of i-1 (this chain:
+    // the forward launch above, or the stand-alone kernel) and gradu(i-1)
     if (i > 0 && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
-    if (fin_branch && !serial && i > 0) {
-      // the older form (PF_GRAPH_FIN=branch): finalize(i-1) as a node of its own on a second side branch, beside the forwards
-      if (hipStreamWaitEvent(c.b, ep[2], 0) != hipSuccess || hipStreamWaitEvent(c.b, ep[1], 0) != hipSuccess)
-        return fail(PF_ERR_HIP, "graph edge failed");
-      pf_problem qq = q;
-      qq.part_half = (i - 1) & 1;
-      PF_TRY(pf_launch_finalize(&qq, 0, 0, c.b, tn_ready), "finalize");
-      if (hipEventRecord(ep[3], c.b) != hipSuccess || hipStreamWaitEvent(s, ep[3], 0) != hipSuccess)
-        return fail(PF_ERR_HIP, "graph edge failed");
-    }
-    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, i > 0 && !(fin_branch && !serial) ? (tn_ready ? 2 : 1) : 0), "node_residual");
+    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, i > 0 ? (tn_ready ? 2 : 1) : 0), "node_residual");
     if (!fuse_gea) {
       PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
       if (!ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
@@ -490,8 +508,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
       if (fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
     }
     PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
-    PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
-    if (!ev_rec(e[2], s)) return fail(PF_ERR_HIP, "graph edge failed");
+    if (!fuse_s2 || i == iters - 1) PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
     // branch A (created after the main chain's nodes of this iteration): gradu behind the last reader of u
     if (!ev_wait(sa, e[0])) return fail(PF_ERR_HIP, "graph edge failed");
     PF_TRY(pf_launch_node_gradu(p, 1, sa), "node_gradu");

@@ -104,6 +104,90 @@ __device__ __forceinline__ float pf_softplus_grad(float z) {
   return ez * __builtin_amdgcn_rcpf(ez + 1.f);
 }
 
+// torch.optim.Adam is a sequence of separately rounded tensor ops (lerp_, mul_, addcmul_, sqrt, div, add,
+// addcdiv_); with the default -ffp-contract=fast hipcc fuses some of them into fma, and not the same ones in
+// every inlined copy (measured: the hipGraph path, which runs the theta update as its own kernel, and the eager
+// path, which runs it inside k_finalize, drifted apart by 1 ulp in theta).  Contraction is switched off in
+// every function that carries optimiser arithmetic.
+#define PF_NO_CONTRACT _Pragma("clang fp contract(off)")
+
+// the two halves of the parameter state (pf_problem.theta_alt): which = 0 theta, 1 m_t, 2 v_t
+__device__ __forceinline__ float* pf_theta_half_ptr(const pf_problem& P, int half, int which) {
+  if (half == 0) return which == 0 ? P.theta : (which == 1 ? P.m_t : P.v_t);
+  return P.theta_alt + (size_t)which * P.n_theta;
+}
+
+// Parameter update (one block, thread q -> parameter q): PF_RG second-level partial rows -> grad_theta[q], then
+// optimizer_theta.step() (solver.py:293-294).  new_theta (LDS, n_theta_active floats) receives the updated parameters
+// when non-null.  The state is read from half `half_in` and stored to half `half_out` (0, 0: in place).
+// skip_stores: compute only (the block-uniform stop flag as loaded by the caller — the loads below are then issued WITH
+// that load instead of behind a branch on it; or a block of the forward launch that only needs its own copy).
+__device__ __forceinline__ void pf_theta_update(const pf_problem& P, int fuse_adam, float* new_theta, int skip_stores = 0,
+                                                int half_in = 0, int half_out = 0) {
+  PF_NO_CONTRACT
+  const float* __restrict__ p2 = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total;
+  const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
+  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
+  const float eps = (float)P.eps;
+  const float* th_i = pf_theta_half_ptr(P, half_in, 0);
+  const float* m_i = pf_theta_half_ptr(P, half_in, 1);
+  const float* v_i = pf_theta_half_ptr(P, half_in, 2);
+  float* th_o = pf_theta_half_ptr(P, half_out, 0);
+  float* m_o = pf_theta_half_ptr(P, half_out, 1);
+  float* v_o = pf_theta_half_ptr(P, half_out, 2);
+  for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
+    const int pi = P.pad_index[q];
+    float th = th_i[q];
+    float m = 0.f, v = 0.f;
+    if (fuse_adam) { m = m_i[q]; v = v_i[q]; }
+    float g = 0.f;
+#pragma unroll
+    for (int r = 0; r < PF_RG; ++r) g += p2[(size_t)r * P.pad_total + pi];
+    if (fuse_adam) {
+      m = m + b1w * (g - m);
+      v = v * b2;
+      v = v + (b2w * g) * g;
+      const float denom = sqrtf(v) / bc2s + eps;
+      th = th + (-step_size) * (m / denom);
+    }
+    if (!skip_stores) {
+      P.grad_theta[q] = g;
+      if (fuse_adam) {
+        m_o[q] = m;
+        v_o[q] = v;
+        th_o[q] = th;
+        P.theta_pad[pi] = th;
+      }
+    }
+    if (new_theta) new_theta[q] = th;
+  }
+}
+
+// theta_norm = sum_k ||theta_k||_2 over ALL parameter tensors (density included), solver.py:319.  The calling wave
+// writes the norms of tensors first, first + step, ... to tnorm[]; each is one wave's lane-strided sum, and the caller
+// adds them in tensor order, so the value does not depend on how many waves share the work.  new_theta: LDS copy of the
+// ACTIVE parameters (or null: read p->theta); parameters that receive no gradient are read from p->theta either way.
+#define PF_MAX_TENSORS 64
+__device__ __forceinline__ void tensor_norms(const pf_problem& P, const float* new_theta, int first, int step,
+                                             float* tnorm) {
+  const int lane = threadIdx.x & 63;
+  for (int t = first; t < P.n_tensors; t += step) {
+    const int lo = P.tensor_off[t], hi = P.tensor_off[t + 1];
+    float s = 0.f;
+    for (int i = lo + lane; i < hi; i += 64) {
+      const float x = (new_theta && i < P.n_theta_active) ? new_theta[i] : P.theta[i];
+      s += x * x;
+    }
+    const float v = sqrtf(pf_wave_sum(s));
+    if (lane == 0) tnorm[t] = v;
+  }
+}
+__device__ __forceinline__ double tensor_norm_total(const pf_problem& P, const float* tnorm) {
+  double tn = 0.0;
+  for (int t = 0; t < P.n_tensors; ++t) tn += (double)tnorm[t];
+  return tn;
+}
+
 // ---- element algebra shared by the node kernels and the fused backward ---------------------------
 struct ElemGeo { float c2, cs, s2, l0; };
 
@@ -285,14 +369,14 @@ PF_DECL_NET_LAUNCHERS(32)
 
 // launchers of pf_net32.hip, one translation unit per register bucket (-DPF_NR=<nr>): nets of width <= 2*nr
 #define PF_DECL_NET32_LAUNCHERS(NRB)                                                       \
-  int pf_launch_net32_forward_##NRB(const pf_problem* p, int which, hipStream_t s);       \
+  int pf_launch_net32_forward_##NRB(const pf_problem* p, int which, hipStream_t s, int s2_half); \
   int pf_launch_net32_backward_##NRB(const pf_problem* p, int which, hipStream_t s);      \
   int pf_launch_net32_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s);  \
-  int pf_launch_net32b_forward_##NRB(const pf_problem* p, int which, hipStream_t s);      \
+  int pf_launch_net32b_forward_##NRB(const pf_problem* p, int which, hipStream_t s, int s2_half); \
   int pf_launch_net32b_backward_##NRB(const pf_problem* p, int which, hipStream_t s);     \
   int pf_launch_net32b_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s); \
-  int pf_launch_net32_forward2_##NRB(const pf_problem* p, hipStream_t s);                 \
-  int pf_launch_net32b_forward2_##NRB(const pf_problem* p, hipStream_t s);
+  int pf_launch_net32_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);    \
+  int pf_launch_net32b_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);
 PF_DECL_NET32_LAUNCHERS(2)
 PF_DECL_NET32_LAUNCHERS(4)
 PF_DECL_NET32_LAUNCHERS(6)

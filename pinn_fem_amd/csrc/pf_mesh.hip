@@ -17,12 +17,8 @@
 #include "pf_common.h"
 #include "pf_net32.h"
 
-// torch.optim.Adam is a sequence of separately rounded tensor ops (lerp_, mul_, addcmul_, sqrt, div, add,
-// addcdiv_); with the default -ffp-contract=fast hipcc fuses some of them into fma, and not the same ones in
-// every inlined copy (measured: the hipGraph path, which runs theta_stage2 as its own kernel, and the eager
-// path, which runs it inside k_finalize, drifted apart by 1 ulp in theta).  Contraction is switched off in
-// every function that carries optimiser arithmetic.
-#define PF_NO_CONTRACT _Pragma("clang fp contract(off)")
+// (PF_NO_CONTRACT, the parameter update pf_theta_update and the theta-norm helpers live in pf_common.h: the MFMA32
+// forward kernels run the same update in their prologue)
 
 namespace {
 
@@ -232,44 +228,6 @@ __global__ __launch_bounds__(256) void k_theta_stage1(pf_problem P, int nb_rows)
   }
 }
 
-// stage 2 (device function, one block): PF_RG partial rows -> grad_theta[q] (+ Adam, refreshed padded
-// image).  new_theta (LDS, n_theta_active floats) receives the updated parameters when non-null.
-// skip_stores: the (block-uniform) stop flag as loaded by the caller — the loads below are then issued WITH that load
-// instead of behind a branch on it (one global round trip less in a kernel that is nothing but round trips).
-__device__ __forceinline__ void theta_stage2(const pf_problem& P, int fuse_adam, float* new_theta, int skip_stores = 0) {
-  PF_NO_CONTRACT
-  const float* __restrict__ p2 = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total;
-  const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
-  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
-  const float eps = (float)P.eps;
-  for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
-    const int pi = P.pad_index[q];
-    float th = P.theta[q];
-    float m = 0.f, v = 0.f;
-    if (fuse_adam) { m = P.m_t[q]; v = P.v_t[q]; }
-    float g = 0.f;
-#pragma unroll
-    for (int r = 0; r < PF_RG; ++r) g += p2[(size_t)r * P.pad_total + pi];
-    if (fuse_adam) {
-      m = m + b1w * (g - m);
-      v = v * b2;
-      v = v + (b2w * g) * g;
-      const float denom = sqrtf(v) / bc2s + eps;
-      th = th + (-step_size) * (m / denom);
-    }
-    if (!skip_stores) {
-      P.grad_theta[q] = g;
-      if (fuse_adam) {
-        P.m_t[q] = m;
-        P.v_t[q] = v;
-        P.theta[q] = th;
-        P.theta_pad[pi] = th;
-      }
-    }
-    if (new_theta) new_theta[q] = th;
-  }
-}
-
 // MFMA32 engine: rebuild the split-f16 operand images of the enabled nets from `th` (the flat active
 // parameters: LDS copy of the values just written, or global theta).  Every thread of the block; no barriers.
 __device__ __forceinline__ void pack_net_ops(const pf_problem& P, const float* th) {
@@ -281,39 +239,35 @@ __device__ __forceinline__ void pack_net_ops(const pf_problem& P, const float* t
   }
 }
 
-// theta_norm = sum_k ||theta_k||_2 over ALL parameter tensors (density included), solver.py:319.  The calling wave
-// writes the norms of tensors first, first + step, ... to tnorm[]; each is one wave's lane-strided sum, and the caller
-// adds them in tensor order, so the value does not depend on how many waves share the work.
-#define PF_MAX_TENSORS 64
-__device__ __forceinline__ void tensor_norms(const pf_problem& P, const float* new_theta, int first, int step,
-                                             float* tnorm) {
-  const int lane = threadIdx.x & 63;
-  for (int t = first; t < P.n_tensors; t += step) {
-    const int lo = P.tensor_off[t], hi = P.tensor_off[t + 1];
-    float s = 0.f;
-    for (int i = lo + lane; i < hi; i += 64) {
-      const float x = (new_theta && i < P.n_theta_active) ? new_theta[i] : P.theta[i];
-      s += x * x;
-    }
-    const float v = sqrtf(pf_wave_sum(s));
-    if (lane == 0) tnorm[t] = v;
-  }
-}
-__device__ __forceinline__ double tensor_norm_total(const pf_problem& P, const float* tnorm) {
-  double tn = 0.0;
-  for (int t = 0; t < P.n_tensors; ++t) tn += (double)tnorm[t];
-  return tn;
-}
-
 // MFMA32 engine (iteration graph): besides the update and the operand images, the block's otherwise idle waves compute
 // the iteration's theta-norm monitor from the LDS copy of the new parameters (state->theta_norm), so that the
 // bookkeeping (finalize_body with tn_ready) has no dependent chain of global loads left.
+// The stand-alone update reads the state from the half the iteration graph left it in (state->theta_half; 0 outside
+// the graph) and always writes half 0; after a stop it only brings a state left in half 1 home.
+__device__ __forceinline__ void theta_update_standalone(const pf_problem& P, int fuse_adam, float* new_theta, int done) {
+  const int half = (fuse_adam && P.theta_alt) ? P.state->theta_half : 0;
+  if (done) {
+    if (half != 0)
+      for (int w = 0; w < 3; ++w) {
+        const float* src = pf_theta_half_ptr(P, 1, w);
+        float* dst = pf_theta_half_ptr(P, 0, w);
+        for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) dst[q] = src[q];
+      }
+  } else {
+    pf_theta_update(P, fuse_adam, new_theta, 0, half, 0);
+  }
+  if (half != 0) {
+    __syncthreads();
+    if (threadIdx.x == 0) P.state->theta_half = 0;
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_theta_stage2(pf_problem P, int fuse_adam) {
   const int done = P.state->done;        // acted on after the loads of the update have been issued
   extern __shared__ float new_theta[];   // n_theta_active floats (MFMA32 engine only)
   __shared__ float tnorm[PF_MAX_TENSORS];
   const bool ops = P.wg_mode == PF_WG_MFMA32 && fuse_adam;
-  theta_stage2(P, fuse_adam, ops ? new_theta : nullptr, done);
+  theta_update_standalone(P, fuse_adam, ops ? new_theta : nullptr, done);
   if (done) return;
   if (ops) {
     __syncthreads();
@@ -356,7 +310,7 @@ __device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int wi
   __shared__ float tnorm[PF_MAX_TENSORS];
   if (with_theta) {
     if (done0) return;
-    theta_stage2(P, mode == 0, new_theta);
+    pf_theta_update(P, mode == 0, new_theta);
     if (mode == 0) {
       __syncthreads();
       pack_net_ops(P, new_theta);
@@ -459,7 +413,7 @@ __global__ __launch_bounds__(1024) void k_shard_pack(pf_problem P, int nb_node, 
   }
   __shared__ double dred[16];
   const pf_mesh& M = P.mesh;
-  if (P.n_theta_active > 0) theta_stage2(P, 0, nullptr);
+  if (P.n_theta_active > 0) pf_theta_update(P, 0, nullptr);
   for (int k = threadIdx.x; k < P.n_iface; k += blockDim.x) buf2[k] = 0.f;
   __syncthreads();
   const float dcoef = P.n_meas_f > 0.f ? P.alpha_data / P.n_meas_f : 0.f;
@@ -574,7 +528,7 @@ __global__ void k_reset(pf_problem P) {
   if (i < P.n_theta) { P.m_t[i] = 0.f; P.v_t[i] = 0.f; }
   if (i == 0) {
     pf_state* S = P.state;
-    S->iter = 0; S->done = 0; S->converged = 0;
+    S->iter = 0; S->done = 0; S->converged = 0; S->theta_half = 0;
     const double bc1 = 1.0 - P.beta1, bc2 = 1.0 - P.beta2;
     S->step_size_u = (float)((double)P.lr_u / bc1);
     S->step_size_t = (float)((double)P.lr_t / bc1);

@@ -42,7 +42,9 @@ __host__ __device__ constexpr int pf_n32_bytes(int n_hidden) { return pf_n32_off
 // Build the image of net `which` from its parameters `th` (torch parameters() order: W1 [w][in], b1, (Wl [w][w],
 // bl)*, Wo [1][w], bo).  Called by every thread of one block (a multiple of 64 threads); no barriers, reads only th.
 // prec 0: split f16 (hi, lo); prec 1: plain bf16 in the hi slots (round to nearest), lo slots zero.
-__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, int prec) {
+// with_bound: also compute the header's backward-scaling bound (only the backward kernels read it: a forward launch that
+// builds the image in its own LDS skips it).
+__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, int prec, bool with_bound = true) {
   const int W = net.width, L = net.n_hidden, IN = net.in_dim;
   const int o_b1 = W * IN, o_h = W * IN + W, per = W * W + W, o_wo = o_h + (L - 1) * per, o_bo = o_wo + W;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -104,7 +106,7 @@ __device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned 
   // bound for the backward scaling: v_L[j] = |wo[j]|, v_{l-1}[k] = sum_j |W_l[j][k]| v_l[j];
   // bound = max_l 4^(L-l) max_k v_l[k]  (|d_l| <= |g_z| v_l since 4 t = 1 - a^2 <= 1).
   // One wave (the block's last, which has the least operand work), v in registers: lane k holds v[k].
-  if ((tid >> 6) == ((nt - 1) >> 6)) {
+  if (with_bound && (tid >> 6) == ((nt - 1) >> 6)) {
     const int lane = tid & 63;
     float v = lane < W ? fabsf(th[o_wo + lane]) : 0.f;
     float bound = 0.f, grow = 1.f;

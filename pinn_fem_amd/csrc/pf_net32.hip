@@ -652,6 +652,40 @@ struct Eng {
 
 };
 
+// ---- the parameter update of the PREVIOUS iteration, run by a forward launch for itself (pf_problem.theta_alt) --------
+// Every block: second-level partial rows -> gradient -> Adam step from state half `half_in` (pf_theta_update: the
+// arithmetic of the stand-alone update kernel, bit for bit) -> its own LDS copy of the new parameters -> the operand
+// images of the enabled nets straight into LDS (img_lds[k]; null: that net's image is not needed by this launch).  Block 0
+// also stores the new state into the other half, the images (with the backward's scaling bound) and the theta-norm
+// monitor to global memory and flips state->theta_half: nothing any block of this launch reads.  Two block barriers.
+__device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half_in, unsigned char* const (&img_lds)[2],
+                                                   float* new_theta, int img_bytes) {
+  const bool lead = blockIdx.x == 0;
+  pf_theta_update(P, 1, new_theta, lead ? 0 : 1, half_in, half_in ^ 1);
+  __syncthreads();
+  for (int k = 0; k < 2; ++k) {
+    if (!P.net[k].enabled) continue;
+    unsigned char* gimg = reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]);
+    if (img_lds[k]) pf_n32_pack(P.net[k], new_theta + P.net[k].theta_off, img_lds[k], P.mlp_dtype, lead);
+    else if (lead) pf_n32_pack(P.net[k], new_theta + P.net[k].theta_off, gimg, P.mlp_dtype, true);
+  }
+  __shared__ float tnorm[PF_MAX_TENSORS];
+  if (lead) {
+    // (the theta norm from the LDS copy, one wave per tensor in turn; inactive parameters come from p->theta)
+    tensor_norms(P, new_theta, threadIdx.x >> 6, blockDim.x >> 6, tnorm);
+  }
+  __syncthreads();
+  if (lead) {
+    for (int k = 0; k < 2; ++k)
+      if (P.net[k].enabled && img_lds[k])
+        copy_image(reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]), img_lds[k], img_bytes);
+    if (threadIdx.x == 0) {
+      P.state->theta_norm = (float)tensor_norm_total(P, tnorm);
+      P.state->theta_half = half_in ^ 1;
+    }
+  }
+}
+
 // ---- forward kernel ----------------------------------------------------------------------------------------
 // One block of 16 waves per CU (four per SIMD); every wave walks 64-element tasks, the block in rounds of 16 tasks.
 // The SIMD arbitrates its waves by age: left alone the oldest runs nearly unimpeded, the waves of a SIMD finish far
@@ -662,13 +696,15 @@ struct Eng {
 // SIMD, item 9).  Lanes past the end work on the last element again (same inputs, same value) and do not store.
 constexpr int FW_THREADS = 1024;
 
+// s2_half >= 0: this launch first runs the parameter update of the previous iteration from that state half
+// (fwd_theta_prologue) and takes its operand image from there instead of from global memory.
 template <int NR, int L, int IN>
-__global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg_arg, int ws) {
+__global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg_arg, int ws, int s2_half) {
   using E = Eng<NR>;
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
   extern __shared__ __align__(16) unsigned char smem[];
   const pf_net net = P.net[which];
-  copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), pf_n32_bytes(L));
+  if (s2_half < 0) copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), pf_n32_bytes(L));
   float* __restrict__ out = which == 0 ? P.prop_e : P.prop_a;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const int grp = (dbg & 32) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // provably wave-uniform
@@ -698,6 +734,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
   if (threadIdx.x == 0) s_done = P.state->done;
   __syncthreads();
   if (s_done || n <= 0) return;
+  if (s2_half >= 0) {
+    unsigned char* const imgs[2] = {which == 0 ? smem : nullptr, which == 1 ? smem : nullptr};
+    fwd_theta_prologue(P, s2_half, imgs, reinterpret_cast<float*>(smem + ((pf_n32_bytes(L) + 255) & ~255)), pf_n32_bytes(L));
+    __syncthreads();
+  }
   const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
   unsigned long long st0 = 0, sr0 = 0;
   if (dbg & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
@@ -749,7 +790,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
 // (all blocks compute the same bits); block 0 stores theta, the moments, the images and the theta-norm monitor — see
 // fwd2_theta_prologue.
 template <int NRE, int NRA, int L, int IN>
-__global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg) {
+__global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg, int s2_half) {
   using EE = Eng<NRE>;
   using EA = Eng<NRA>;
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
@@ -758,8 +799,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   const unsigned char* __restrict__ img_e = smem;
   const unsigned char* __restrict__ img_a = smem + IMGP;
   const pf_net net_e = P.net[0], net_a = P.net[1];
-  copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[0]), IMG);
-  copy_image(smem + IMGP, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[1]), IMG);
+  if (s2_half < 0) {
+    copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[0]), IMG);
+    copy_image(smem + IMGP, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[1]), IMG);
+  }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const int grp = (dbg & 32) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   const int n = P.mesh.n_elems;
@@ -778,6 +821,11 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   if (threadIdx.x == 0) s_done = P.state->done;
   __syncthreads();
   if (s_done || n <= 0) return;
+  if (s2_half >= 0) {
+    unsigned char* const imgs[2] = {smem, smem + IMGP};
+    fwd_theta_prologue(P, s2_half, imgs, reinterpret_cast<float*>(smem + 2 * IMGP), IMG);
+    __syncthreads();
+  }
   const float bo_e = reinterpret_cast<const float*>(img_e + pf_n32_off_bo())[0];
   const float bo_a = reinterpret_cast<const float*>(img_a + pf_n32_off_bo())[0];
   for (int r = 0; r < rounds; ++r, task += per_round) {
@@ -1037,7 +1085,7 @@ __global__ __launch_bounds__((Eng<NR>::template bw_threads<L, GEA>())) void k_ne
 }
 
 template <int L, int IN>
-int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
+int launch_fwd(const pf_problem* p, int which, hipStream_t s, int s2_half) {
   constexpr int NR = PF_NR;
   const int n = p->mesh.n_elems;
   int nb = (n + FW_THREADS - 1) / FW_THREADS;
@@ -1046,7 +1094,10 @@ int launch_fwd(const pf_problem* p, int which, hipStream_t s) {
   if (nb < 1) nb = 1;
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;   // timing experiments only
   const int ws = p->elem_k != nullptr ? 1 : 0;
-  hipLaunchKernelGGL((k_net32_forward<NR, L, IN>), dim3(nb), dim3(FW_THREADS), pf_n32_bytes(L), s, *p, which, dbg, ws);
+  const size_t lds = s2_half < 0 ? (size_t)pf_n32_bytes(L)
+                                 : (size_t)((pf_n32_bytes(L) + 255) & ~255) + (size_t)p->n_theta_active * sizeof(float);
+  if (lds > 64000) { pf_set_error("too many trainable parameters for the fused theta update"); return PF_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL((k_net32_forward<NR, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, which, dbg, ws, s2_half);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 
@@ -1070,7 +1121,7 @@ int launch_bwd_gea(const pf_problem* p, int which, hipStream_t s) { return launc
 
 // fused forward of both nets: the E net's bucket is this translation unit's PF_NR, the A net's bucket is dispatched here
 template <int NRA, int L, int IN>
-int launch_fwd2_t(const pf_problem* p, hipStream_t s) {
+int launch_fwd2_t(const pf_problem* p, hipStream_t s, int s2_half) {
   constexpr int NRE = PF_NR;
   const int n = p->mesh.n_elems;
   int nb = (n + FW_THREADS - 1) / FW_THREADS;
@@ -1078,20 +1129,21 @@ int launch_fwd2_t(const pf_problem* p, hipStream_t s) {
   if (nb > cap) nb = cap;
   if (nb < 1) nb = 1;
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;
-  const size_t lds = 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255);
-  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg);
+  const size_t lds = 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255) + (s2_half < 0 ? 0 : (size_t)p->n_theta_active * sizeof(float));
+  if (lds > 64000) { pf_set_error("too many trainable parameters for the fused theta update"); return PF_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>
-int launch_fwd2(const pf_problem* p, hipStream_t s) {
+int launch_fwd2(const pf_problem* p, hipStream_t s, int s2_half) {
   switch (pf_net32_bucket(p->net[1].width)) {
-    case 2: return launch_fwd2_t<2, L, IN>(p, s);
-    case 4: return launch_fwd2_t<4, L, IN>(p, s);
-    case 6: return launch_fwd2_t<6, L, IN>(p, s);
-    case 8: return launch_fwd2_t<8, L, IN>(p, s);
-    case 10: return launch_fwd2_t<10, L, IN>(p, s);
-    case 12: return launch_fwd2_t<12, L, IN>(p, s);
-    case 15: return launch_fwd2_t<15, L, IN>(p, s);
+    case 2: return launch_fwd2_t<2, L, IN>(p, s, s2_half);
+    case 4: return launch_fwd2_t<4, L, IN>(p, s, s2_half);
+    case 6: return launch_fwd2_t<6, L, IN>(p, s, s2_half);
+    case 8: return launch_fwd2_t<8, L, IN>(p, s, s2_half);
+    case 10: return launch_fwd2_t<10, L, IN>(p, s, s2_half);
+    case 12: return launch_fwd2_t<12, L, IN>(p, s, s2_half);
+    case 15: return launch_fwd2_t<15, L, IN>(p, s, s2_half);
   }
   pf_set_error("MFMA32 engine: area net width outside 1..30");
   return PF_ERR_UNSUPPORTED;
@@ -1127,8 +1179,20 @@ int launch_fwd2(const pf_problem* p, hipStream_t s) {
   pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)"); \
   return PF_ERR_UNSUPPORTED;
 
-int PF_N32_SYM(forward_)(const pf_problem* p, int which, hipStream_t s) {
-  PF_DISPATCH(launch_fwd)
+int PF_N32_SYM(forward_)(const pf_problem* p, int which, hipStream_t s, int s2_half) {
+  const pf_net& net = p->net[which];
+  const int L = net.n_hidden, IN = net.in_dim;
+  if (IN == 3) {
+    if (L == 1) return launch_fwd<1, 3>(p, which, s, s2_half);
+    if (L == 2) return launch_fwd<2, 3>(p, which, s, s2_half);
+    if (L == 3) return launch_fwd<3, 3>(p, which, s, s2_half);
+  } else if (IN == 2) {
+    if (L == 1) return launch_fwd<1, 2>(p, which, s, s2_half);
+    if (L == 2) return launch_fwd<2, 2>(p, which, s, s2_half);
+    if (L == 3) return launch_fwd<3, 2>(p, which, s, s2_half);
+  }
+  pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)");
+  return PF_ERR_UNSUPPORTED;
 }
 int PF_N32_SYM(backward_)(const pf_problem* p, int which, hipStream_t s) {
   PF_DISPATCH(launch_bwd)
@@ -1138,16 +1202,16 @@ int PF_N32_SYM(backward_gea_)(const pf_problem* p, int which, hipStream_t s) {
 }
 #else
 // both nets enabled, same number of hidden layers and the same inputs (pf_api.hip checks): young net of THIS bucket
-int PF_N32_SYM(forward2_)(const pf_problem* p, hipStream_t s) {
+int PF_N32_SYM(forward2_)(const pf_problem* p, hipStream_t s, int s2_half) {
   const int L = p->net[0].n_hidden, IN = p->net[0].in_dim;
   if (IN == 3) {
-    if (L == 1) return launch_fwd2<1, 3>(p, s);
-    if (L == 2) return launch_fwd2<2, 3>(p, s);
-    if (L == 3) return launch_fwd2<3, 3>(p, s);
+    if (L == 1) return launch_fwd2<1, 3>(p, s, s2_half);
+    if (L == 2) return launch_fwd2<2, 3>(p, s, s2_half);
+    if (L == 3) return launch_fwd2<3, 3>(p, s, s2_half);
   } else if (IN == 2) {
-    if (L == 1) return launch_fwd2<1, 2>(p, s);
-    if (L == 2) return launch_fwd2<2, 2>(p, s);
-    if (L == 3) return launch_fwd2<3, 2>(p, s);
+    if (L == 1) return launch_fwd2<1, 2>(p, s, s2_half);
+    if (L == 2) return launch_fwd2<2, 2>(p, s, s2_half);
+    if (L == 3) return launch_fwd2<3, 2>(p, s, s2_half);
   }
   pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)");
   return PF_ERR_UNSUPPORTED;

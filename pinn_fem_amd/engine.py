@@ -156,6 +156,8 @@ class HipEngine:
         self.m_t = torch.zeros(max(self.n_theta, 1), **f32)
         self.v_t = torch.zeros(max(self.n_theta, 1), **f32)
         self.theta_pad = torch.zeros(max(self.pad_total, 1), **f32)
+        # second half of (theta, m_t, v_t): lets the iteration graph fold the parameter update into the next forward launch
+        self.theta_alt = torch.zeros(3 * max(self.n_theta, 1), **f32)
         # two halves: the iteration graph ping-pongs between them (pf_problem.prop_double); everything else
         # uses the first
         self.prop_e = torch.zeros(2 * ne, **f32)
@@ -251,6 +253,7 @@ class HipEngine:
         P.coord_exp = self.coord_exp
         P.mlp_dtype = _capi.PF_MLP_BF16 if self.mlp_dtype == "bf16" else _capi.PF_MLP_F32
         P.elem_k = self.elem_k.data_ptr() if self.elem_k is not None else None
+        P.theta_alt = self.theta_alt.data_ptr() if self.n_theta_active > 0 else None
         P.adj_other = self.adj_other.data_ptr()
         self._configured = True
 
