@@ -1045,8 +1045,8 @@ def test_backward_running_rescale_vs_oracle(direction):
     "falling" keeps the first S while the later tasks' operands shrink towards the f16 underflow range.  Gradients
     against the oracle (float64 sums).  The per-element terms alternate in sign here (g_z follows the residual, a
     difference of neighbouring element forces), so the sums cancel by orders of magnitude: the error is measured
-    against sum_e |term_e| per entry, the scale of a float32 accumulation — bound 2e-5 (float32 noise of the terms
-    themselves: 1e-6 ... 9e-6 on every engine, the exact-f32 one included)."""
+    against sum_e |term_e| per entry, the scale of a float32 accumulation — bound 5e-6 (measured <= 5e-7 on the
+    MFMA32 engine, 3e-7 on the exact-f32 engine: profiles/r03_rescale_diag.txt)."""
     n = 20_000
     # coordinates in [0, 3]: with h = 1 the layer-1 units of the far elements saturate (|z| ~ 10^4), where the reference's
     # tanh backward 1 - y*y (y = tanh in float32, one ulp from 1) is quantised in steps of 1.2e-7 while the kernels'
@@ -1074,8 +1074,8 @@ def test_backward_running_rescale_vs_oracle(direction):
         asum = asum.reshape(want.shape)
         ratio = float(np.max(np.abs(got - want) / np.maximum(asum, 1e-300)))
         worst = max(worst, ratio)
-        assert ratio < 2e-5, (direction, k, ratio)
-        assert np.max(np.abs(got - want)) < 1e-5 * np.max(asum), (direction, k)
+        assert ratio < 5e-6, (direction, k, ratio)
+        assert np.max(np.abs(got - want)) < 5e-6 * np.max(asum), (direction, k)
     print(f"running rescale [{direction}]: worst |err| / sum|terms| = {worst:.2e}")
     assert abs(losses["loss_total"] - ref.loss_total) < 2e-5 * abs(ref.loss_total)
 
@@ -1083,9 +1083,12 @@ def test_backward_running_rescale_vs_oracle(direction):
 @pytest.mark.parametrize("lam", [1.0e3, 3.0e4])
 def test_large_load_factor_gradients_vs_oracle(lam):
     """the load factor is an INPUT of the nets and so an operand of the layer-1 gradient tile, where
-    it travels as split f16; it carries its own power-of-two scale (host-derived, like the coordinates') — with the fixed
+    it travels as split f16; it carries its own power-of-two scale (from |lam|, like the coordinates') — with the fixed
     factor 256 of round 2 it overflowed f16 from |lam| >= 256 and dW1[:,0] came out wrong without any sign.  Small
-    layer-1 weights keep tanh off saturation so that the gradient is not round-off."""
+    load-factor weights keep tanh off saturation.  Every column of W1 on its own scale (the load-factor column's gradient
+    is lam times the bias gradient): the MFMA32 engine against the exact-f32 engine within 5e-5 of the column maximum, and
+    both against the oracle within 5e-3 (x reaches 300 on this fixture: some layer-1 units are close to saturation, where
+    the reference's 1 - y*y is quantised in steps of 1.2e-7 and the kernels' r (1 - r) is not)."""
     rec = load_npz("step_chain300_ex4shape.npz")
     theta = theta_from(rec)
     for k in (0, 6):
@@ -1094,19 +1097,21 @@ def test_large_load_factor_gradients_vs_oracle(lam):
     model = product_model(rec["nodes"], rec["elements"], rec["loads"], rec["fixed"], 2, (20, 15, 10), (1.0, 1.0, 1.0), theta)
     pb = mesh_problem(dict(rec, **{f"theta_{i}": t for i, t in enumerate(theta)}), (20, 15, 10), (1.0, 1.0, 1.0))
     ref = orc.loss_and_grads(pb, orc.element_geometry(pb), rec["u"], lam, 1.0, 100.0, acc64=True)
+    active = [g for g in ref.grad_theta if g is not None]
+    got = {}
     for wg in (3, 2):
         eng = _engine(model, rec["meas_vals"], rec["meas_dofs"], wg)
         losses, gu, gt = eng.loss_and_grads(torch.from_numpy(rec["u"]), lam, 1.0, 100.0)
-        gt = gt.cpu().numpy()
-        active = [g for g in ref.grad_theta if g is not None]
-        for k, (got, want) in enumerate(zip(_theta_tensors_like(ref.grad_theta, gt), active)):
-            assert np.max(np.abs(got - want)) < 1e-3 * max(np.max(np.abs(want)), 1e-30), (wg, k)
-        # every column of W1 on its own scale (the load-factor column's gradient is lam times the bias gradient)
-        for k in (0, 6):
-            for c in range(3):
-                got = _theta_tensors_like(ref.grad_theta, gt)[k][:, c]
-                want = active[k][:, c]
-                assert np.max(np.abs(got - want)) < 1e-3 * np.max(np.abs(want)), (wg, k, c)
+        got[wg] = _theta_tensors_like(ref.grad_theta, gt.cpu().numpy().copy())
+        assert np.all(np.isfinite(gt.cpu().numpy()))
+    for k, want in enumerate(active):
+        w2 = want.reshape(want.shape[0], -1) if want.ndim > 1 else want.reshape(1, -1).T
+        a3, a2 = got[3][k].reshape(w2.shape), got[2][k].reshape(w2.shape)
+        for c in range(w2.shape[1]):
+            scale = max(np.max(np.abs(w2[:, c])), 1e-30)
+            assert np.max(np.abs(a3[:, c] - a2[:, c])) < 5e-5 * scale, (k, c)
+            assert np.max(np.abs(a3[:, c] - w2[:, c])) < 5e-3 * scale, (k, c)
+            assert np.max(np.abs(a2[:, c] - w2[:, c])) < 5e-3 * scale, (k, c)
 
 
 def test_beyond_infinity_cache_1e7_elements():
