@@ -659,10 +659,16 @@ struct Eng {
 // also stores the new state into the other half, the images (with the backward's scaling bound) and the theta-norm
 // monitor to global memory and flips state->theta_half: nothing any block of this launch reads.  Two block barriers.
 __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half_in, unsigned char* const (&img_lds)[2],
-                                                   float* new_theta, int img_bytes) {
+                                                   float* new_theta, int img_bytes, int* s_done) {
   const bool lead = blockIdx.x == 0;
-  pf_theta_update(P, 1, new_theta, lead ? 0 : 1, half_in, half_in ^ 1);
+  // The stop flag is stable while a forward launch runs (the bookkeeping that raises it is ordered behind it), so the lead
+  // block may read it for itself, and every block's update loads leave together with the block's one flag read instead
+  // of behind a barrier on it.
+  const int done0 = lead ? P.state->done : 1;
+  if (threadIdx.x == 0) *s_done = P.state->done;
+  pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1);
   __syncthreads();
+  if (*s_done) return;
   for (int k = 0; k < 2; ++k) {
     if (!P.net[k].enabled) continue;
     unsigned char* gimg = reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]);
@@ -731,14 +737,15 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
   // the stop flag, one read per block (the bookkeeping that raises it may run beside this launch: a block whose waves
   // disagreed would part ways before the lockstep barriers below)
   __shared__ int s_done;
-  if (threadIdx.x == 0) s_done = P.state->done;
-  __syncthreads();
-  if (s_done || n <= 0) return;
   if (s2_half >= 0) {
     unsigned char* const imgs[2] = {which == 0 ? smem : nullptr, which == 1 ? smem : nullptr};
-    fwd_theta_prologue(P, s2_half, imgs, reinterpret_cast<float*>(smem + ((pf_n32_bytes(L) + 255) & ~255)), pf_n32_bytes(L));
+    fwd_theta_prologue(P, s2_half, imgs, reinterpret_cast<float*>(smem + ((pf_n32_bytes(L) + 255) & ~255)), pf_n32_bytes(L),
+                       &s_done);
+  } else {
+    if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
   }
+  if (s_done || n <= 0) return;
   const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
   unsigned long long st0 = 0, sr0 = 0;
   if (dbg & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
@@ -818,14 +825,14 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
     gn = load_geo(P.mesh.egeo, e0);
   }
   __shared__ int s_done;
-  if (threadIdx.x == 0) s_done = P.state->done;
-  __syncthreads();
-  if (s_done || n <= 0) return;
   if (s2_half >= 0) {
     unsigned char* const imgs[2] = {smem, smem + IMGP};
-    fwd_theta_prologue(P, s2_half, imgs, reinterpret_cast<float*>(smem + 2 * IMGP), IMG);
+    fwd_theta_prologue(P, s2_half, imgs, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done);
+  } else {
+    if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
   }
+  if (s_done || n <= 0) return;
   const float bo_e = reinterpret_cast<const float*>(img_e + pf_n32_off_bo())[0];
   const float bo_a = reinterpret_cast<const float*>(img_a + pf_n32_off_bo())[0];
   for (int r = 0; r < rounds; ++r, task += per_round) {
