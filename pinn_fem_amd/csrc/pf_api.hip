@@ -199,6 +199,27 @@ static int net_backward_gea(const pf_problem* p, int which, hipStream_t s) {
   PF_WIDTH_SWITCH(pf_launch_net44_backward_gea_)
 }
 
+// both backward passes (the first with the fused element adjoint) in ONE launch, two phases (pf_net32.hip:
+// k_net32_backward2).  PF_FUSE_BWD=0: experiment knob.
+static bool can_fuse_backward(const pf_problem* p) {
+  static const int knob = getenv("PF_FUSE_BWD") ? atoi(getenv("PF_FUSE_BWD")) : 1;
+  return knob != 0 && can_fuse_forward(p) && p->net[0].n_hidden == 2 && fuse_gea_for(p);
+}
+static int net_backward2(const pf_problem* p, hipStream_t s) {
+#define PF_NR0_SWITCH_B(PREFIX)                                   \
+  switch (pf_net32_bucket(p->net[0].width)) {                     \
+    case 2: return PREFIX##2(p, s);                               \
+    case 4: return PREFIX##4(p, s);                               \
+    case 6: return PREFIX##6(p, s);                               \
+    case 8: return PREFIX##8(p, s);                               \
+    case 10: return PREFIX##10(p, s);                             \
+    case 12: return PREFIX##12(p, s);                             \
+    case 15: return PREFIX##15(p, s);                             \
+  }                                                               \
+  return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
+  if (p->mlp_dtype == PF_MLP_BF16) { PF_NR0_SWITCH_B(pf_launch_net32b_backward2_) }
+  PF_NR0_SWITCH_B(pf_launch_net32_backward2_)
+}
 // element adjoint + backward of every enabled net; with the MFMA44 engine the adjoint is fused into
 // the first net's backward kernel
 
@@ -374,10 +395,12 @@ static int enqueue_iteration(const pf_problem* p, int fuse_adam, int finalize_mo
   PF_MARK(K_ADJOINT);
   if (any_net && !fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
   PF_MARK(K_BWD_E);
-  if (p->net[0].enabled)
+  const bool bwd2 = can_fuse_backward(p);             // both nets in the first slot's launch; the second slot stays empty
+  if (bwd2) PF_TRY(net_backward2(p, s), "net_backward2");
+  else if (p->net[0].enabled)
     PF_TRY(fuse_gea && first == 0 ? net_backward_gea(p, 0, s) : net_backward(p, 0, s), "net_backward");
   PF_MARK(K_BWD_A);
-  if (p->net[1].enabled)
+  if (!bwd2 && p->net[1].enabled)
     PF_TRY(fuse_gea && first == 1 ? net_backward_gea(p, 1, s) : net_backward(p, 1, s), "net_backward");
   PF_MARK(K_GRADU);
   PF_TRY(pf_launch_node_gradu(p, fuse_adam, s), "node_gradu");
@@ -502,10 +525,16 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
       PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
       if (!ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
     }
-    for (int k = 0; k < 2; ++k) {
-      if (!p->net[k].enabled) continue;
-      PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
-      if (fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
+    if (can_fuse_backward(p)) {
+      // both backward passes in one launch: gradu (its fork) then runs beside theta stage 1 and the NEXT forward launch
+      PF_TRY(net_backward2(p, s), "net_backward2");
+      if (!ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
+    } else {
+      for (int k = 0; k < 2; ++k) {
+        if (!p->net[k].enabled) continue;
+        PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
+        if (fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
+      }
     }
     PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
     if (!fuse_s2 || i == iters - 1) PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
@@ -678,10 +707,14 @@ int pf_shard_backward(const pf_problem* p, float* buf, const float* u2_local, vo
     const pf_problem q = own_view(p);
     const bool fuse_gea = fuse_gea_for(&q);
     const int first = q.net[0].enabled ? 0 : 1;
-    if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(&q, s), "elem_adjoint");
-    for (int k = 0; k < 2; ++k)
-      if (q.net[k].enabled)
-        PF_TRY(fuse_gea && k == first ? net_backward_gea(&q, k, s) : net_backward(&q, k, s), "net_backward");
+    if (can_fuse_backward(&q)) {
+      PF_TRY(net_backward2(&q, s), "net_backward2");
+    } else {
+      if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(&q, s), "elem_adjoint");
+      for (int k = 0; k < 2; ++k)
+        if (q.net[k].enabled)
+          PF_TRY(fuse_gea && k == first ? net_backward_gea(&q, k, s) : net_backward(&q, k, s), "net_backward");
+    }
     PF_TRY(pf_launch_theta_stage1(&q, s), "theta_stage1");
   }
   PF_TRY(pf_launch_shard_pack(p, buf, u2_local, s), "shard_pack");
@@ -728,14 +761,19 @@ int pf_shard_graph_capture(const pf_problem* p, int iters, float* buf, float* u2
         const pf_problem q = own_view(p);
         const bool fuse_gea = fuse_gea_for(&q);
         const int first = q.net[0].enabled ? 0 : 1;
-        if (!fuse_gea) {
-          PF_TRY(pf_launch_elem_adjoint(&q, s), "elem_adjoint");
+        if (can_fuse_backward(&q)) {
+          PF_TRY(net_backward2(&q, s), "net_backward2");
           if (!mark()) return fail(PF_ERR_HIP, "graph edge failed");
-        }
-        for (int k = 0; k < 2; ++k) {
-          if (!q.net[k].enabled) continue;
-          PF_TRY(fuse_gea && k == first ? net_backward_gea(&q, k, s) : net_backward(&q, k, s), "net_backward");
-          if (fuse_gea && k == first && !mark()) return fail(PF_ERR_HIP, "graph edge failed");
+        } else {
+          if (!fuse_gea) {
+            PF_TRY(pf_launch_elem_adjoint(&q, s), "elem_adjoint");
+            if (!mark()) return fail(PF_ERR_HIP, "graph edge failed");
+          }
+          for (int k = 0; k < 2; ++k) {
+            if (!q.net[k].enabled) continue;
+            PF_TRY(fuse_gea && k == first ? net_backward_gea(&q, k, s) : net_backward(&q, k, s), "net_backward");
+            if (fuse_gea && k == first && !mark()) return fail(PF_ERR_HIP, "graph edge failed");
+          }
         }
         PF_TRY(pf_launch_theta_stage1(&q, s), "theta_stage1");
       }

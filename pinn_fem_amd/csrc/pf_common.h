@@ -376,7 +376,9 @@ PF_DECL_NET_LAUNCHERS(32)
   int pf_launch_net32b_backward_##NRB(const pf_problem* p, int which, hipStream_t s);     \
   int pf_launch_net32b_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s); \
   int pf_launch_net32_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);    \
-  int pf_launch_net32b_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);
+  int pf_launch_net32b_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);   \
+  int pf_launch_net32_backward2_##NRB(const pf_problem* p, hipStream_t s);                \
+  int pf_launch_net32b_backward2_##NRB(const pf_problem* p, hipStream_t s);
 PF_DECL_NET32_LAUNCHERS(2)
 PF_DECL_NET32_LAUNCHERS(4)
 PF_DECL_NET32_LAUNCHERS(6)

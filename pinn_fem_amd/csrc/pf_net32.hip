@@ -872,16 +872,18 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
 
 // GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the other net's
 // backward.  Partial gradient row of the block: the padded image of pf_common.h (what theta_stage1 sums).
+// One net's backward over the block's tasks, as a phase of a launch: `smem` = this net's operand image in LDS (copied by
+// the caller, no barrier needed before the call), `cst` = the constant blocks (CONST_BYTES of this bucket), `wscr` = the
+// block's wave scratches (the write-out staging reuses them).  Ends with the block's partial gradient row written; the
+// caller places a block barrier between two phases that share cst / wscr.
 template <int NR, int L, int IN, bool GEA>
-__global__ __launch_bounds__((Eng<NR>::template bw_threads<L, GEA>())) void k_net32_backward(pf_problem P, int which, int hp, int dbg_arg) {
+__device__ __forceinline__ void backward_phase(const pf_problem& P, int which, int hp, int dbg, const unsigned char* smem,
+                                               unsigned char* cst, unsigned char* wscr) {
   using E = Eng<NR>;
   constexpr int CONST_BYTES = E::CONST_BYTES, WAVE_SCRATCH = E::WAVE_SCRATCH, REGION = E::REGION, NPK = E::NPK;
   constexpr bool COMPACT = E::COMPACT;
   typedef typename E::WriteBase WriteBase;
-  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
-  extern __shared__ __align__(16) unsigned char smem[];
   constexpr int DIM = IN - 1;
-  constexpr int IMG = pf_n32_bytes(L);
   const pf_net net = P.net[which];
   const pf_net onet = P.net[1 - which];
   const float* __restrict__ other = which == 0 ? P.prop_a : P.prop_e;
@@ -889,10 +891,7 @@ __global__ __launch_bounds__((Eng<NR>::template bw_threads<L, GEA>())) void k_ne
   const int n = P.mesh.n_elems;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const int h = lane >> 5;
-  copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), IMG);
-  constexpr int IMGPAD = (IMG + 255) & ~255;
-  unsigned char* cst = smem + IMGPAD;                  // constant blocks (see CONST_BYTES)
-  unsigned char* scratch = smem + IMGPAD + CONST_BYTES + wv * WAVE_SCRATCH;
+  unsigned char* scratch = wscr + wv * WAVE_SCRATCH;
   for (int i = threadIdx.x; i < CONST_BYTES / 4; i += blockDim.x) reinterpret_cast<unsigned*>(cst)[i] = 0u;
   for (int i = lane; i < WAVE_SCRATCH / 16; i += 64) reinterpret_cast<uint4*>(scratch)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
@@ -911,10 +910,7 @@ __global__ __launch_bounds__((Eng<NR>::template bw_threads<L, GEA>())) void k_ne
     task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(base + lane, n - 1));
     if (GEA) nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(base + stride + lane, n - 1)];
   }
-  __shared__ int s_done;                         // the stop flag, one read per block (block-uniform by construction)
-  if (threadIdx.x == 0) s_done = P.state->done;
-  __syncthreads();
-  if (s_done != 0 || n <= 0) return;
+  __syncthreads();                               // (image, constant blocks and scratch are in place)
   task_fetch_b<IN, GEA>(nxt, P);
 
   // block-uniform scalars: keep them in SGPRs (the kernel runs at its register budget)
@@ -1024,7 +1020,7 @@ __global__ __launch_bounds__((Eng<NR>::template bw_threads<L, GEA>())) void k_ne
 
   // ---- write-out: fixed-order sums over the block's waves -> this block's partial gradient row ---------------------------
   __syncthreads();
-  float* stage = reinterpret_cast<float*>(smem + IMGPAD + CONST_BYTES);   // reuses the scratch: [wave][1024]
+  float* stage = reinterpret_cast<float*>(wscr);   // reuses the scratch: [wave][1024]
   const int W = net.width;
   float* __restrict__ prow = P.partials + PF_PART_WG + (size_t)blockIdx.x * P.pad_total + net.pad_off;
   const int padc = pf_pad_count(hp, L);
@@ -1091,6 +1087,58 @@ __global__ __launch_bounds__((Eng<NR>::template bw_threads<L, GEA>())) void k_ne
   }
 }
 
+
+// GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the other net's
+// backward.  Partial gradient row of the block: the padded image of pf_common.h (what theta_stage1 sums).
+template <int NR, int L, int IN, bool GEA>
+__global__ __launch_bounds__((Eng<NR>::template bw_threads<L, GEA>())) void k_net32_backward(pf_problem P, int which, int hp, int dbg_arg) {
+  using E = Eng<NR>;
+  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int IMG = pf_n32_bytes(L), IMGPAD = (IMG + 255) & ~255;
+  __shared__ int s_done;                         // the stop flag, one read per block
+  if (threadIdx.x == 0) s_done = P.state->done;
+  copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), IMG);
+  __syncthreads();
+  if (s_done != 0 || P.mesh.n_elems <= 0) return;
+  backward_phase<NR, L, IN, GEA>(P, which, hp, dbg, smem, smem + IMGPAD, smem + IMGPAD + E::CONST_BYTES);
+}
+
+// ---- backward of BOTH nets in one launch: two phases --------------------------------------------------------------------
+// Phase 1 = the young net's backward with the fused element adjoint, phase 2 = the area net's, each exactly the
+// single-net kernel's work (a wave walks the same tasks in both, so the adjoint it stored in phase 1 is its own when
+// it reads it back in phase 2).  The nets are NOT interleaved per task: the gradient tiles of one net plus the paired
+// recompute already fill the 256 registers a wave may hold at two waves per SIMD (234 for the 20-wide net).  What the
+// one launch saves is a launch floor, a prologue and the drain of the first kernel: blocks that finish phase 1 early start
+// phase 2 at once.
+template <int NRE, int NRA, int L, int IN>
+constexpr int bw2_threads() {
+  return Eng<NRE>::template bw_threads<L, true>() < Eng<NRA>::template bw_threads<L, false>()
+             ? Eng<NRE>::template bw_threads<L, true>() : Eng<NRA>::template bw_threads<L, false>();
+}
+template <int NRE, int NRA>
+constexpr int bw2_const_bytes() { return Eng<NRE>::CONST_BYTES > Eng<NRA>::CONST_BYTES ? Eng<NRE>::CONST_BYTES : Eng<NRA>::CONST_BYTES; }
+template <int NRE, int NRA>
+constexpr int bw2_wave_scratch() { return Eng<NRE>::WAVE_SCRATCH > Eng<NRA>::WAVE_SCRATCH ? Eng<NRE>::WAVE_SCRATCH : Eng<NRA>::WAVE_SCRATCH; }
+
+template <int NRE, int NRA, int L, int IN>
+__global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_backward2(pf_problem P, int hp_e, int hp_a, int dbg_arg) {
+  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int IMG = pf_n32_bytes(L), IMGPAD = (IMG + 255) & ~255;
+  __shared__ int s_done;
+  if (threadIdx.x == 0) s_done = P.state->done;
+  copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[0]), IMG);
+  copy_image(smem + IMGPAD, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[1]), IMG);
+  __syncthreads();
+  if (s_done != 0 || P.mesh.n_elems <= 0) return;
+  unsigned char* cst = smem + 2 * IMGPAD;
+  unsigned char* wscr = cst + bw2_const_bytes<NRE, NRA>();
+  backward_phase<NRE, L, IN, true>(P, 0, hp_e, dbg, smem, cst, wscr);
+  __syncthreads();                               // the write-out staging of phase 1 is read; scratch and constants are re-initialised
+  backward_phase<NRA, L, IN, false>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr);
+}
+
 template <int L, int IN>
 int launch_fwd(const pf_problem* p, int which, hipStream_t s, int s2_half) {
   constexpr int NR = PF_NR;
@@ -1151,6 +1199,34 @@ int launch_fwd2(const pf_problem* p, hipStream_t s, int s2_half) {
     case 10: return launch_fwd2_t<10, L, IN>(p, s, s2_half);
     case 12: return launch_fwd2_t<12, L, IN>(p, s, s2_half);
     case 15: return launch_fwd2_t<15, L, IN>(p, s, s2_half);
+  }
+  pf_set_error("MFMA32 engine: area net width outside 1..30");
+  return PF_ERR_UNSUPPORTED;
+}
+
+// fused backward of both nets (two phases): E net of this translation unit's bucket, A net's bucket dispatched here
+template <int NRA, int L, int IN>
+int launch_bwd2_t(const pf_problem* p, hipStream_t s) {
+  constexpr int NRE = PF_NR;
+  const int nb = pf_net_blocks(p);
+  const int hp_e = ((p->net[0].width + 3) / 4) * 4, hp_a = ((p->net[1].width + 3) / 4) * 4;
+  constexpr int THREADS = bw2_threads<NRE, NRA, L, IN>();
+  const size_t lds = 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255) + bw2_const_bytes<NRE, NRA>() +
+                     (size_t)(THREADS / 64) * bw2_wave_scratch<NRE, NRA>();
+  static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;
+  hipLaunchKernelGGL((k_net32_backward2<NRE, NRA, L, IN>), dim3(nb), dim3(THREADS), lds, s, *p, hp_e, hp_a, dbg);
+  return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
+}
+template <int L, int IN>
+int launch_bwd2(const pf_problem* p, hipStream_t s) {
+  switch (pf_net32_bucket(p->net[1].width)) {
+    case 2: return launch_bwd2_t<2, L, IN>(p, s);
+    case 4: return launch_bwd2_t<4, L, IN>(p, s);
+    case 6: return launch_bwd2_t<6, L, IN>(p, s);
+    case 8: return launch_bwd2_t<8, L, IN>(p, s);
+    case 10: return launch_bwd2_t<10, L, IN>(p, s);
+    case 12: return launch_bwd2_t<12, L, IN>(p, s);
+    case 15: return launch_bwd2_t<15, L, IN>(p, s);
   }
   pf_set_error("MFMA32 engine: area net width outside 1..30");
   return PF_ERR_UNSUPPORTED;
@@ -1221,6 +1297,16 @@ int PF_N32_SYM(forward2_)(const pf_problem* p, hipStream_t s, int s2_half) {
     if (L == 3) return launch_fwd2<3, 2>(p, s, s2_half);
   }
   pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)");
+  return PF_ERR_UNSUPPORTED;
+}
+// Two hidden layers only (the reference's SimpleNN default and every example): with one or three the two phases in one
+// kernel no longer fit the register budget of their block shapes without spilling (checked in the compiler's asm), and
+// a spill reload in the task loop costs more than a launch boundary — those shapes keep the two launches.
+int PF_N32_SYM(backward2_)(const pf_problem* p, hipStream_t s) {
+  const int L = p->net[0].n_hidden, IN = p->net[0].in_dim;
+  if (L == 2 && IN == 3) return launch_bwd2<2, 3>(p, s);
+  if (L == 2 && IN == 2) return launch_bwd2<2, 2>(p, s);
+  pf_set_error("fused backward: two hidden layers only");
   return PF_ERR_UNSUPPORTED;
 }
 #endif
