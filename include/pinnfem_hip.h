@@ -99,7 +99,8 @@ typedef struct pf_state {
   float step_size_u, step_size_t, bc2_sqrt, _pad2;
   /* last iteration's monitors (solver.py:304-320) */
   float loss_total, loss_physics, loss_data, u_norm, residual_norm, theta_norm;
-  float _pad3[2];
+  int32_t u_half;      /* 1: the current displacements are in p->u_alt (only between the kernels of an iteration graph) */
+  float _pad3;
 } pf_state;
 
 #define PF_HIST_COLS 6 /* loss_total, loss_physics, loss_data, u_norm, residual_norm, theta_norm */
@@ -183,6 +184,12 @@ typedef struct pf_problem {
    * state->theta_half.  The single-block update launch and one kernel boundary leave the critical path; a replay ends
    * with a stand-alone update that brings the state back to half 0. */
   float* theta_alt;
+  /* second displacement vector [n_dofs], or NULL.  With it the iteration graph lets the displacement update of
+   * iteration t (pf_node_gradu + Adam) WRITE the other vector than the one the residual and the element adjoint of t
+   * read, so the update runs beside the whole backward launch instead of behind the adjoint's last read of u; the
+   * vectors swap roles every iteration, an even number of iterations per replay ends in p->u, and a replay cut short by
+   * the stop test copies the result home (state->u_half). */
+  float* u_alt;
   /* per CSR entry of mesh.adj: the node at the OTHER end of that element ([adj_ptr[n_nodes]] int32).  With it the node
    * kernels fetch a neighbour's values one dependent load earlier (adj -> value instead of adj -> conn -> value) and
    * two incidences at a time; NULL: they go through mesh.conn. */

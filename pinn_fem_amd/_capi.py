@@ -56,7 +56,7 @@ class PfState(C.Structure):
         ("_pad2", C.c_float),
         ("loss_total", C.c_float), ("loss_physics", C.c_float), ("loss_data", C.c_float),
         ("u_norm", C.c_float), ("residual_norm", C.c_float), ("theta_norm", C.c_float),
-        ("_pad3", C.c_float * 2),
+        ("u_half", C.c_int32), ("_pad3", C.c_float),
     ]
 
 
@@ -83,7 +83,7 @@ class PfProblem(C.Structure):
         ("n_shared", C.c_int32), ("n_iface", C.c_int32),
         ("own_lo", C.c_int32), ("own_hi", C.c_int32), ("part_half", C.c_int32), ("prop_double", C.c_int32),
         ("net_op", C.c_void_p), ("op_off", C.c_int32 * 2), ("coord_exp", C.c_int32), ("mlp_dtype", C.c_int32),
-        ("elem_k", C.c_void_p), ("theta_alt", C.c_void_p), ("adj_other", C.c_void_p),
+        ("elem_k", C.c_void_p), ("theta_alt", C.c_void_p), ("u_alt", C.c_void_p), ("adj_other", C.c_void_p),
     ]
 
 

@@ -9,7 +9,8 @@
 // launchers from pf_mesh.hip
 int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_loss, hipStream_t s, int fin_prev = 0);
 int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s);
-int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared = 0);
+int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared = 0, float* u_out = nullptr);
+int pf_launch_u_home(const pf_problem* p, hipStream_t s);
 int pf_launch_shard_pack(const pf_problem* p, float* buf2, const float* u2_local, hipStream_t s);
 int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* u2_local, hipStream_t s);
 int pf_launch_shard_flush(const pf_problem* p, const float* u2, hipStream_t s);
@@ -498,6 +499,12 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   // ping-pongs between its two halves so that block 0's stores never meet another block's loads.  Only the replay's
   // last iteration keeps the stand-alone update, which also brings the state back to half 0.
   const bool fuse_s2 = can_fuse_theta_update(p);
+  // Displacement vectors ping-pong too (pf_problem.u_alt; DAG form, even replay length): the update of iteration i reads
+  // U[i & 1] like the residual and the element adjoint of i and WRITES U[(i + 1) & 1], so it forks right behind the
+  // residual and runs beside the whole backward launch.  PF_GRAPH_UPP=0: experiment knob (in place, fork behind the
+  // adjoint's last read of u).
+  static const bool upp_knob = !(getenv("PF_GRAPH_UPP") && atoi(getenv("PF_GRAPH_UPP")) == 0);
+  const bool upp = !serial && upp_knob && p->u_alt != nullptr && (iters % 2) == 0;
   for (int i = 0; i < iters; ++i) {
     hipEvent_t* e = c.ev + PF_CAP_EV * i;
     hipEvent_t* ep = c.ev + PF_CAP_EV * (i - 1);
@@ -513,6 +520,11 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
       if (q.elem_k) q.elem_k += (size_t)q.mesh.n_elems * (q.mesh.dim == 2 ? 3 : 1);
     }
     q.part_half = i & 1;
+    float* u_next = nullptr;
+    if (upp) {
+      u_next = (i & 1) ? q.u : q.u_alt;
+      if (i & 1) q.u = q.u_alt;                       // what this iteration's kernels READ
+    }
     if (i > 0 && !pingpong && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
     // (both nets in one launch where the engine has it; else one after the other: side by side on two branches they
     // measured slower, the same issue pipe, and the second one writes the stiffness records from both)
@@ -521,30 +533,32 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     // the forward launch above, or the stand-alone kernel) and gradu(i-1)
     if (i > 0 && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
     PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, i > 0 ? (tn_ready ? 2 : 1) : 0), "node_residual");
+    if (upp && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");      // gradu forks here
     if (!fuse_gea) {
       PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
-      if (!ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
+      if (!upp && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
     }
     if (can_fuse_backward(p)) {
-      // both backward passes in one launch: gradu (its fork) then runs beside theta stage 1 and the NEXT forward launch
+      // both backward passes in one launch (without the second displacement vector gradu can only fork behind it)
       PF_TRY(net_backward2(p, s), "net_backward2");
-      if (!ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
+      if (!upp && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
     } else {
       for (int k = 0; k < 2; ++k) {
         if (!p->net[k].enabled) continue;
         PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
-        if (fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
+        if (!upp && fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
       }
     }
     PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
     if (!fuse_s2 || i == iters - 1) PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
     // branch A (created after the main chain's nodes of this iteration): gradu behind the last reader of u
     if (!ev_wait(sa, e[0])) return fail(PF_ERR_HIP, "graph edge failed");
-    PF_TRY(pf_launch_node_gradu(p, 1, sa), "node_gradu");
+    PF_TRY(pf_launch_node_gradu(p, 1, sa, 0, u_next), "node_gradu");
     if (!ev_rec(e[1], sa)) return fail(PF_ERR_HIP, "graph edge failed");
   }
   // finalize of the last iteration: behind stage 2 (this chain) and the last gradu
   if (!ev_wait(s, c.ev[PF_CAP_EV * (iters - 1) + 1])) return fail(PF_ERR_HIP, "graph join failed");
+  if (upp) PF_TRY(pf_launch_u_home(p, s), "u_home");      // (only a stop in mid-replay leaves anything to copy)
   {
     pf_problem q = *p;
     q.part_half = (iters - 1) & 1;

@@ -150,10 +150,14 @@ __global__ __launch_bounds__(256) void k_elem_adjoint(pf_problem P) {
 // ---- dL/du (+ Adam on u, BC clamp, ||u_free||^2) ------------------------------------------------
 // skip_shared (multi-GPU): shared dofs are left alone; their gradient is completed by the second
 // all-reduce and pf_shard_update_shared steps them.
+// u_out (iteration graph, FUSE_ADAM only): the updated displacements go to this vector instead of P.u, EVERY dof of it
+// (the other kernels of the iteration still read P.u); out_alt = 1 when u_out is pf_problem.u_alt.
 template <int DIM, bool FUSE_ADAM>
-__global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void k_node_gradu(pf_problem P, int skip_shared) {
+__global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void k_node_gradu(pf_problem P, int skip_shared,
+                                                                                                   float* __restrict__ u_out, int out_alt) {
   PF_NO_CONTRACT
   if (P.state->done) return;
+  if (FUSE_ADAM && u_out && blockIdx.x == 0 && threadIdx.x == 0) P.state->u_half = out_alt;
   __shared__ float red[16];
   const pf_mesh& M = P.mesh;
   const float step_size = P.state->step_size_u, bc2s = P.state->bc2_sqrt;
@@ -181,7 +185,8 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
         if (fl & PF_DOF_FIXED) {
           // solver.py:297-298: u[fixed] = 0 after the step.  The Adam moments of a fixed dof only ever
           // feed that dof's own (discarded) update, so they are dead state: not loaded, not stored.
-          if (uo != 0.f) P.u[dof] = 0.f;
+          if (u_out) u_out[dof] = 0.f;
+          else if (uo != 0.f) P.u[dof] = 0.f;
           continue;
         }
         // torch.optim.Adam single-tensor arithmetic (torch/optim/adam.py)
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
         if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
         P.m_u[dof] = m;
         P.v_u[dof] = v;
-        P.u[dof] = uo;
+        (u_out ? u_out : P.u)[dof] = uo;
       }
     }
   }
@@ -528,7 +533,7 @@ __global__ void k_reset(pf_problem P) {
   if (i < P.n_theta) { P.m_t[i] = 0.f; P.v_t[i] = 0.f; }
   if (i == 0) {
     pf_state* S = P.state;
-    S->iter = 0; S->done = 0; S->converged = 0; S->theta_half = 0;
+    S->iter = 0; S->done = 0; S->converged = 0; S->theta_half = 0; S->u_half = 0;
     const double bc1 = 1.0 - P.beta1, bc2 = 1.0 - P.beta2;
     S->step_size_u = (float)((double)P.lr_u / bc1);
     S->step_size_t = (float)((double)P.lr_t / bc1);
@@ -637,16 +642,30 @@ int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s) {
   return PF_CHECK_LAUNCH();
 }
 
-int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared) {
+int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared, float* u_out) {
   const int nb = pf_node_blocks(p->mesh.n_nodes);
   const dim3 g(nb), b(PF_NODE_THREADS);
+  const int out_alt = u_out != nullptr && u_out == p->u_alt ? 1 : 0;
   if (p->mesh.dim == 2) {
-    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<2, true>), g, b, 0, s, *p, skip_shared);
-    else hipLaunchKernelGGL((k_node_gradu<2, false>), g, b, 0, s, *p, skip_shared);
+    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<2, true>), g, b, 0, s, *p, skip_shared, u_out, out_alt);
+    else hipLaunchKernelGGL((k_node_gradu<2, false>), g, b, 0, s, *p, skip_shared, (float*)nullptr, 0);
   } else {
-    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<1, true>), g, b, 0, s, *p, skip_shared);
-    else hipLaunchKernelGGL((k_node_gradu<1, false>), g, b, 0, s, *p, skip_shared);
+    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<1, true>), g, b, 0, s, *p, skip_shared, u_out, out_alt);
+    else hipLaunchKernelGGL((k_node_gradu<1, false>), g, b, 0, s, *p, skip_shared, (float*)nullptr, 0);
   }
+  return PF_CHECK_LAUNCH();
+}
+
+// end of a replay of the iteration graph: a stop raised in mid-replay can leave the final displacements in u_alt
+// (state->u_half): bring them home.  Nothing to do otherwise (one uniform load per block).
+__global__ __launch_bounds__(256) void k_u_home(pf_problem P) {
+  if (!P.state->u_half || !P.u_alt) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.mesh.n_dofs; i += gridDim.x * blockDim.x) P.u[i] = P.u_alt[i];
+}
+int pf_launch_u_home(const pf_problem* p, hipStream_t s) {
+  int nb = (p->mesh.n_dofs + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_u_home, dim3(nb), dim3(256), 0, s, *p);
   return PF_CHECK_LAUNCH();
 }
 

@@ -151,6 +151,7 @@ class HipEngine:
         f32 = dict(dtype=torch.float32, device=dev)
         nd, ne = hp.n_dofs, max(hp.n_elems, 1)
         self.u = torch.zeros(nd, **f32)
+        self.u_alt = torch.zeros(nd, **f32)      # the iteration graph's second displacement vector (pf_problem.u_alt)
         self.m_u = torch.zeros(nd, **f32)
         self.v_u = torch.zeros(nd, **f32)
         self.m_t = torch.zeros(max(self.n_theta, 1), **f32)
@@ -254,6 +255,7 @@ class HipEngine:
         P.mlp_dtype = _capi.PF_MLP_BF16 if self.mlp_dtype == "bf16" else _capi.PF_MLP_F32
         P.elem_k = self.elem_k.data_ptr() if self.elem_k is not None else None
         P.theta_alt = self.theta_alt.data_ptr() if self.n_theta_active > 0 else None
+        P.u_alt = self.u_alt.data_ptr()
         P.adj_other = self.adj_other.data_ptr()
         self._configured = True
 
