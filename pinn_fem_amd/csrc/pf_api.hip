@@ -206,16 +206,22 @@ static bool can_fuse_backward(const pf_problem* p) {
   static const int knob = getenv("PF_FUSE_BWD") ? atoi(getenv("PF_FUSE_BWD")) : 1;
   return knob != 0 && can_fuse_forward(p) && p->net[0].n_hidden == 2 && fuse_gea_for(p);
 }
-static int net_backward2(const pf_problem* p, hipStream_t s) {
+// reduce_rows != 0: the launch also does theta stage 1 (the last block of every row group sums the group's rows into the
+// second-level row, the arithmetic of k_theta_stage1): no pf_launch_theta_stage1 behind it.  PF_FUSE_S1=0: experiment knob.
+static bool fuse_s1_knob() {
+  static const int knob = getenv("PF_FUSE_S1") ? atoi(getenv("PF_FUSE_S1")) : 1;
+  return knob != 0;
+}
+static int net_backward2(const pf_problem* p, hipStream_t s, int reduce_rows = 0) {
 #define PF_NR0_SWITCH_B(PREFIX)                                   \
   switch (pf_net32_bucket(p->net[0].width)) {                     \
-    case 2: return PREFIX##2(p, s);                               \
-    case 4: return PREFIX##4(p, s);                               \
-    case 6: return PREFIX##6(p, s);                               \
-    case 8: return PREFIX##8(p, s);                               \
-    case 10: return PREFIX##10(p, s);                             \
-    case 12: return PREFIX##12(p, s);                             \
-    case 15: return PREFIX##15(p, s);                             \
+    case 2: return PREFIX##2(p, s, reduce_rows);                  \
+    case 4: return PREFIX##4(p, s, reduce_rows);                  \
+    case 6: return PREFIX##6(p, s, reduce_rows);                  \
+    case 8: return PREFIX##8(p, s, reduce_rows);                  \
+    case 10: return PREFIX##10(p, s, reduce_rows);                \
+    case 12: return PREFIX##12(p, s, reduce_rows);                \
+    case 15: return PREFIX##15(p, s, reduce_rows);                \
   }                                                               \
   return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
   if (p->mlp_dtype == PF_MLP_BF16) { PF_NR0_SWITCH_B(pf_launch_net32b_backward2_) }
@@ -290,7 +296,7 @@ int pf_net_op_count(int in_dim, int width, int n_hidden) {
 
 long long pf_partials_count(const pf_problem* p) {
   if (!p) return PF_ERR_ARG;
-  return (long long)PF_PART_WG + ((long long)p->n_part_blocks + PF_RG) * (long long)p->pad_total;
+  return (long long)PF_PART_WG + ((long long)p->n_part_blocks + PF_RG) * (long long)p->pad_total + PF_TICKETS;
 }
 
 int pf_pack_theta(const pf_problem* p, void* stream) {
@@ -540,7 +546,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     }
     if (can_fuse_backward(p)) {
       // both backward passes in one launch (without the second displacement vector gradu can only fork behind it)
-      PF_TRY(net_backward2(p, s), "net_backward2");
+      PF_TRY(net_backward2(p, s, fuse_s1_knob() ? 1 : 0), "net_backward2");
       if (!upp && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
     } else {
       for (int k = 0; k < 2; ++k) {
@@ -549,7 +555,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
         if (!upp && fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
       }
     }
-    PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
+    if (!(can_fuse_backward(p) && fuse_s1_knob())) PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
     if (!fuse_s2 || i == iters - 1) PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
     // branch A (created after the main chain's nodes of this iteration): gradu behind the last reader of u
     if (!ev_wait(sa, e[0])) return fail(PF_ERR_HIP, "graph edge failed");

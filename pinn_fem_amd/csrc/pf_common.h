@@ -17,8 +17,10 @@
 #define PF_PART_D2H(h) ((h) ? 4 * PF_NODE_SLOTS : PF_NODE_SLOTS)
 #define PF_PART_U2 (2 * PF_NODE_SLOTS)
 #define PF_PART_WG (5 * PF_NODE_SLOTS)
-// after the [n_part_blocks][pad_total] rows: [PF_RG][pad_total] second-level partial rows
+// after the [n_part_blocks][pad_total] rows: [PF_RG][pad_total] second-level partial rows, then PF_RG + 16 int32 row-group
+// tickets (zero between launches) of the fused backward launch, which does the first reduction level itself
 #define PF_RG 16
+#define PF_TICKETS (PF_RG + 16)
 
 // elements per block-iteration of the net kernels (2 waves)
 #define PF_NET_THREADS 128
@@ -377,8 +379,8 @@ PF_DECL_NET_LAUNCHERS(32)
   int pf_launch_net32b_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s); \
   int pf_launch_net32_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);    \
   int pf_launch_net32b_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);   \
-  int pf_launch_net32_backward2_##NRB(const pf_problem* p, hipStream_t s);                \
-  int pf_launch_net32b_backward2_##NRB(const pf_problem* p, hipStream_t s);
+  int pf_launch_net32_backward2_##NRB(const pf_problem* p, hipStream_t s, int reduce_rows); \
+  int pf_launch_net32b_backward2_##NRB(const pf_problem* p, hipStream_t s, int reduce_rows);
 PF_DECL_NET32_LAUNCHERS(2)
 PF_DECL_NET32_LAUNCHERS(4)
 PF_DECL_NET32_LAUNCHERS(6)

@@ -872,6 +872,50 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
 
 // GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the other net's
 // backward.  Partial gradient row of the block: the padded image of pf_common.h (what theta_stage1 sums).
+// Stores of a block's partial gradient row: agent-scope write-through (global_store ... sc1).  The fused backward launch
+// hands the rows to the LAST block of each row group inside the launch (rows_reduce_last below), and a hand-off without a
+// release fence needs every handed-off byte stored this way (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms).
+__device__ __forceinline__ void row_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float row_load(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// First level of the parameter-gradient reduction INSIDE the backward launch (what the k_theta_stage1 launch does
+// otherwise, to the bit: same row groups, same summation order): the block's row is complete and stored; every wave drains
+// its stores, the block takes a ticket of its row group, and the block that draws the group's last ticket sums the
+// group's rows into the group's second-level row.  No block ever waits for another one.  tickets: PF_RG counters, zero
+// between launches (the last block of a group resets its counter).
+__device__ __forceinline__ void rows_reduce_last(const pf_problem& P, int nb_rows) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's row stores have left
+  __syncthreads();
+  const int rpg = (nb_rows + PF_RG - 1) / PF_RG;
+  const int g = (int)blockIdx.x / rpg;
+  const int r0 = g * rpg, r1 = min(r0 + rpg, nb_rows);
+  int* tickets = reinterpret_cast<int*>(P.partials + PF_PART_WG + ((size_t)P.n_part_blocks + PF_RG) * P.pad_total);
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(tickets + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = old == (r1 - r0) - 1;
+    if (s_last) __hip_atomic_store(tickets + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // the arithmetic of k_theta_stage1 for row group g: four interleaved row sums per column, combined (0 + 1) + (2 + 3)
+  float* __restrict__ out = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total + (size_t)g * P.pad_total;
+  for (int col = threadIdx.x; col < P.pad_total; col += blockDim.x) {
+    const float* rows = P.partials + PF_PART_WG + col;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; r += 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (r + k < r1) a[k] += row_load(rows + (size_t)(r + k) * P.pad_total);
+    }
+    out[col] = (a[0] + a[1]) + (a[2] + a[3]);
+  }
+}
+
 // One net's backward over the block's tasks, as a phase of a launch: `smem` = this net's operand image in LDS (copied by
 // the caller, no barrier needed before the call), `cst` = the constant blocks (CONST_BYTES of this bucket), `wscr` = the
 // block's wave scratches (the write-out staging reuses them).  Ends with the block's partial gradient row written; the
@@ -1024,7 +1068,7 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
   const int W = net.width;
   float* __restrict__ prow = P.partials + PF_PART_WG + (size_t)blockIdx.x * P.pad_total + net.pad_off;
   const int padc = pf_pad_count(hp, L);
-  for (int i = threadIdx.x; i < padc; i += blockDim.x) prow[i] = 0.f;
+  for (int i = threadIdx.x; i < padc; i += blockDim.x) row_store(prow + i, 0.f);
   // scale of d_l relative to the true gradient after the 1/S: 4^(L-l)
   sfor<0, L>([&](auto l) {
     constexpr int LL = l + 1;                      // layer whose weight gradient tile T[LL-1] holds
@@ -1055,7 +1099,7 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
         if (c < IN) { dst = j * 4 + c; k *= c == 0 ? kl : kx; }
         else if (c == IN) dst = j * 4 + IN;                                           // bias (input 1.0)
       }
-      if (dst >= 0) prow[dst] = t / k;
+      if (dst >= 0) row_store(prow + dst, t / k);
     }
   });
   // output unit row: sum over the 32 columns of each half-wave, then over the waves
@@ -1077,13 +1121,13 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
     if (r < NR && u < W) {
       float t = 0.f;
       for (int q = 0; q < waves; ++q) t += stage[q * 64 + hh * 16 + r];
-      prow[pf_pad_wo(hp, L) + u] = t * (1.0f / PF_N32_KA);
+      row_store(prow + pf_pad_wo(hp, L) + u, t * (1.0f / PF_N32_KA));
     }
   }
   if (threadIdx.x == 32) {
     float t = 0.f;
     for (int q = 0; q < waves; ++q) t += stage[waves * 64 + q];
-    prow[pf_pad_wo(hp, L) + hp] = t;
+    row_store(prow + pf_pad_wo(hp, L) + hp, t);
   }
 }
 
@@ -1122,7 +1166,8 @@ template <int NRE, int NRA>
 constexpr int bw2_wave_scratch() { return Eng<NRE>::WAVE_SCRATCH > Eng<NRA>::WAVE_SCRATCH ? Eng<NRE>::WAVE_SCRATCH : Eng<NRA>::WAVE_SCRATCH; }
 
 template <int NRE, int NRA, int L, int IN>
-__global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_backward2(pf_problem P, int hp_e, int hp_a, int dbg_arg) {
+__global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_backward2(pf_problem P, int hp_e, int hp_a, int dbg_arg,
+                                                                                     int reduce_rows) {
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int IMG = pf_n32_bytes(L), IMGPAD = (IMG + 255) & ~255;
@@ -1137,6 +1182,8 @@ __global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_back
   backward_phase<NRE, L, IN, true>(P, 0, hp_e, dbg, smem, cst, wscr);
   __syncthreads();                               // the write-out staging of phase 1 is read; scratch and constants are re-initialised
   backward_phase<NRA, L, IN, false>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr);
+  // reduce_rows: the launch is also theta stage 1 (the last block of every row group sums the group's rows)
+  if (reduce_rows) rows_reduce_last(P, (int)gridDim.x);
 }
 
 template <int L, int IN>
@@ -1206,7 +1253,7 @@ int launch_fwd2(const pf_problem* p, hipStream_t s, int s2_half) {
 
 // fused backward of both nets (two phases): E net of this translation unit's bucket, A net's bucket dispatched here
 template <int NRA, int L, int IN>
-int launch_bwd2_t(const pf_problem* p, hipStream_t s) {
+int launch_bwd2_t(const pf_problem* p, hipStream_t s, int reduce_rows) {
   constexpr int NRE = PF_NR;
   const int nb = pf_net_blocks(p);
   const int hp_e = ((p->net[0].width + 3) / 4) * 4, hp_a = ((p->net[1].width + 3) / 4) * 4;
@@ -1214,19 +1261,19 @@ int launch_bwd2_t(const pf_problem* p, hipStream_t s) {
   const size_t lds = 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255) + bw2_const_bytes<NRE, NRA>() +
                      (size_t)(THREADS / 64) * bw2_wave_scratch<NRE, NRA>();
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;
-  hipLaunchKernelGGL((k_net32_backward2<NRE, NRA, L, IN>), dim3(nb), dim3(THREADS), lds, s, *p, hp_e, hp_a, dbg);
+  hipLaunchKernelGGL((k_net32_backward2<NRE, NRA, L, IN>), dim3(nb), dim3(THREADS), lds, s, *p, hp_e, hp_a, dbg, reduce_rows);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>
-int launch_bwd2(const pf_problem* p, hipStream_t s) {
+int launch_bwd2(const pf_problem* p, hipStream_t s, int reduce_rows) {
   switch (pf_net32_bucket(p->net[1].width)) {
-    case 2: return launch_bwd2_t<2, L, IN>(p, s);
-    case 4: return launch_bwd2_t<4, L, IN>(p, s);
-    case 6: return launch_bwd2_t<6, L, IN>(p, s);
-    case 8: return launch_bwd2_t<8, L, IN>(p, s);
-    case 10: return launch_bwd2_t<10, L, IN>(p, s);
-    case 12: return launch_bwd2_t<12, L, IN>(p, s);
-    case 15: return launch_bwd2_t<15, L, IN>(p, s);
+    case 2: return launch_bwd2_t<2, L, IN>(p, s, reduce_rows);
+    case 4: return launch_bwd2_t<4, L, IN>(p, s, reduce_rows);
+    case 6: return launch_bwd2_t<6, L, IN>(p, s, reduce_rows);
+    case 8: return launch_bwd2_t<8, L, IN>(p, s, reduce_rows);
+    case 10: return launch_bwd2_t<10, L, IN>(p, s, reduce_rows);
+    case 12: return launch_bwd2_t<12, L, IN>(p, s, reduce_rows);
+    case 15: return launch_bwd2_t<15, L, IN>(p, s, reduce_rows);
   }
   pf_set_error("MFMA32 engine: area net width outside 1..30");
   return PF_ERR_UNSUPPORTED;
@@ -1302,10 +1349,10 @@ int PF_N32_SYM(forward2_)(const pf_problem* p, hipStream_t s, int s2_half) {
 // Two hidden layers only (the reference's SimpleNN default and every example): with one or three the two phases in one
 // kernel no longer fit the register budget of their block shapes without spilling (checked in the compiler's asm), and
 // a spill reload in the task loop costs more than a launch boundary — those shapes keep the two launches.
-int PF_N32_SYM(backward2_)(const pf_problem* p, hipStream_t s) {
+int PF_N32_SYM(backward2_)(const pf_problem* p, hipStream_t s, int reduce_rows) {
   const int L = p->net[0].n_hidden, IN = p->net[0].in_dim;
-  if (L == 2 && IN == 3) return launch_bwd2<2, 3>(p, s);
-  if (L == 2 && IN == 2) return launch_bwd2<2, 2>(p, s);
+  if (L == 2 && IN == 3) return launch_bwd2<2, 3>(p, s, reduce_rows);
+  if (L == 2 && IN == 2) return launch_bwd2<2, 2>(p, s, reduce_rows);
   pf_set_error("fused backward: two hidden layers only");
   return PF_ERR_UNSUPPORTED;
 }
