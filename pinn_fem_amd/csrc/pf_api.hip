@@ -207,9 +207,12 @@ static bool can_fuse_backward(const pf_problem* p) {
   return knob != 0 && can_fuse_forward(p) && p->net[0].n_hidden == 2 && fuse_gea_for(p);
 }
 // reduce_rows != 0: the launch also does theta stage 1 (the last block of every row group sums the group's rows into the
-// second-level row, the arithmetic of k_theta_stage1): no pf_launch_theta_stage1 behind it.  PF_FUSE_S1=0: experiment knob.
+// second-level row, the arithmetic of k_theta_stage1): no pf_launch_theta_stage1 behind it.  OFF by default
+// (PF_FUSE_S1=1 switches it on): bit-identical, but measured SLOWER on MI355X — the backward launch grew from 79 to 92 us
+// (every block drains its stores, takes a ticket, and the 16 last blocks read 16 rows each through sc1 loads) for a 7 us
+// kernel saved: 0.1547 against 0.1500 ms per iteration (profiles/r03_ab.txt).
 static bool fuse_s1_knob() {
-  static const int knob = getenv("PF_FUSE_S1") ? atoi(getenv("PF_FUSE_S1")) : 1;
+  static const int knob = getenv("PF_FUSE_S1") ? atoi(getenv("PF_FUSE_S1")) : 0;
   return knob != 0;
 }
 static int net_backward2(const pf_problem* p, hipStream_t s, int reduce_rows = 0) {
