@@ -291,7 +291,7 @@ def main():
 
     n_local = args.elems if args.total_elems <= 0 else args.total_elems // world
     lr_t = 5e-4 if args.workload == "ex4" else 1e-3
-    cfg = SolverConfig(max_iterations=args.warmup + (2 + max(args.repeat, 0)) * args.steps + 64, tolerance=0.0,
+    cfg = SolverConfig(max_iterations=max(args.warmup, 50) + (2 + max(args.repeat, 0)) * args.steps + 64, tolerance=0.0,
                        learning_rate_u=0.01, learning_rate_theta=lr_t, alpha_physics=1.0, alpha_data=100.0)
     if world == 1:
         from pinn_fem_amd.engine import HipEngine
@@ -300,7 +300,10 @@ def main():
         eng.begin(None, 0.1, cfg, want_history=False)
         eng.prepare_graph()                           # capture + instantiate: never inside the timed region
         gk = eng.GRAPH_ITERS
-        n_warm = ((max(args.warmup, 1) + gk - 1) // gk) * gk   # >= W, whole replays: the graph is uploaded and hot
+        # >= W, whole replays (the graph is uploaded and hot), and at least 50 iterations (~8 ms): the chip's clocks are still
+        # settling during the first replays after the event pass (the first 20-step region read 3-5 us per step above the
+        # following ones); the number actually run is reported as warmup_iterations_run
+        n_warm = ((max(args.warmup, 50) + gk - 1) // gk) * gk
         run_warm = lambda n: eng.iterate(n)
         run_timed = lambda n: eng.iterate(n)          # hipGraph replay (10 iterations per graph)
         run_events = lambda n: eng.iterate_timed(n)   # eager launches with HIP events around every kernel
@@ -311,7 +314,7 @@ def main():
         eng = ShardedChainEngine(n_local, args.workload, rank, world, dev)
         eng.begin(None, 0.1, cfg)
         eng.prepare()                                 # the C driver's RCCL communicator (collective)
-        n_warm = max(args.warmup, 1)
+        n_warm = max(args.warmup, 50)
         run_warm = lambda n: eng.iterate(n)
         run_timed = lambda n: eng.iterate(n)
         run_events = lambda n: eng.iterate_timed(n)
@@ -401,13 +404,18 @@ def main():
         total_elems = n_local * world
         value = total_elems * args.steps / dt
         names = _capi.KERNEL_SLOT_NAMES
+        fused = (eng if world == 1 else eng.backend.eng).fusion_info()
         dom = int(np.argmax(slot_ms))
         # roofline of the dominant kernel.  The net_backward kernels are bound by f32 matrix/vector
         # throughput (dense MLP GEMM work); the node kernels by HBM.
         if names[dom].startswith("net_backward"):
-            w = widths[0] if names[dom].endswith("young") else widths[1]
-            ach = net_flops(w) * n_local / (slot_ms[dom] * 1e-3) / 1e12
-            roof = {"kernel": names[dom], "bound": "mfma", "achieved": ach, "peak": F32_PEAK_TFLOPS,
+            both = bool(fused & _capi.PF_FUSED_BACKWARD)         # ONE launch carries the backward of both nets
+            if both:
+                flops, kname = sum(net_flops(w) for w in widths[:2] if w is not None), "net_backward (young + area, one launch)"
+            else:
+                flops, kname = net_flops(widths[0] if names[dom].endswith("young") else widths[1]), names[dom]
+            ach = flops * n_local / (slot_ms[dom] * 1e-3) / 1e12
+            roof = {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": ach / F32_PEAK_TFLOPS, "traffic": None,
                     "avg_launch_ms": float(slot_ms[dom]),
                     "note": "algorithmic float32 flops (forward recompute + backward) against the dense f32 peak; the "
@@ -423,13 +431,14 @@ def main():
         # HBM traffic of the dominant kernel: rocprofv3 PMC (FETCH_SIZE, WRITE_SIZE in separate passes,
         # gfx950 correction applied) of this same command, committed under profiles/
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as f:
                 tr = json.load(f)["kernels"]
-            key = {"net_backward_young": "k_net32_backward<2, 3, true>", "net_backward_area": "k_net32_backward<2, 3, false>",
+            key = {"net_backward_young": "k_net32_backward2<10, 8, 2, 3>" if fused & _capi.PF_FUSED_BACKWARD
+                   else "k_net32_backward<10, 2, 3, true>", "net_backward_area": "k_net32_backward<8, 2, 3, false>",
                    "node_residual": "k_node_residual<2>", "node_gradu_adam": "k_node_gradu<2, true>"}.get(names[dom])
             if key in tr and n_local == 1_000_000 and args.workload == "ex4":
                 roof["traffic"] = tr[key]["hbm_bytes_corrected"]
-                roof["traffic_source"] = "profiles/r02_traffic.json (rocprofv3 --pmc, per launch)"
+                roof["traffic_source"] = "profiles/r03_traffic.json (rocprofv3 --pmc, per launch)"
         except Exception:
             pass
         it_bytes = ALGO_BYTES_PER_EVAL * value / world / 1e9
@@ -455,6 +464,11 @@ def main():
                         "value_at_median": total_elems * 1e3 / float(np.median(rep_ms))} if rep_ms else None),
             "ms_per_step_eager_with_events": dt_events / args.steps * 1e3,
             "kernel_ms": {n: float(m) for n, m in zip(names, slot_ms)},
+            "fused_launches": {"forward_young+area": bool(fused & _capi.PF_FUSED_FORWARD),
+                               "backward_young+area": bool(fused & _capi.PF_FUSED_BACKWARD),
+                               "theta_update_in_next_forward (graph)": bool(fused & _capi.PF_FUSED_THETA_UPDATE),
+                               "displacement_ping_pong (graph)": bool(fused & _capi.PF_FUSED_U_PINGPONG),
+                               "note": "a fused launch is booked on the first of its two kernel_ms slots"},
             "roofline": roof,
         }
         if world > 1:

@@ -24,6 +24,7 @@ PF_COMM_ID_BYTES = 128
 PF_MAX_NODE_BLOCKS = 4096
 PF_NODE_SLOTS = PF_MAX_NODE_BLOCKS + 8
 PF_KERNEL_SLOTS = 9
+PF_FUSED_FORWARD, PF_FUSED_BACKWARD, PF_FUSED_THETA_UPDATE, PF_FUSED_U_PINGPONG = 1, 2, 4, 8
 KERNEL_SLOT_NAMES = ("net_forward_young", "net_forward_area", "node_residual", "elem_adjoint",
                      "net_backward_young", "net_backward_area", "node_gradu_adam", "theta_reduce_adam",
                      "finalize")
@@ -99,6 +100,7 @@ SYMBOLS = {
     "pf_sizeof": (C.c_int, [C.c_int]),
     "pf_net_op_count": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "pf_partials_count": (C.c_longlong, [_PP]),
+    "pf_fusion_info": (C.c_int, [_PP]),
     "pf_pack_theta": (C.c_int, [_PP, C.c_void_p]),
     "pf_net_forward": (C.c_int, [_PP, C.c_int, C.c_void_p]),
     "pf_internal_force": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -25,6 +25,10 @@ int pf_launch_adam(float* param, const float* grad, float* m, float* v, int n, i
 int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s);
 int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s);
 
+// below this many elements the iteration graph is a plain chain: the kernels are then too short to hide anything behind,
+// the branches' fork/join cost (~5 us each against ~1.5 us for a plain boundary) would only add to a launch-bound iteration
+#define PF_GRAPH_DAG_MIN_ELEMS 200000   /* measured crossover between 1e5 (chain 0.061 vs DAG 0.067 ms) and 3e5 (0.099 vs 0.092) */
+
 static thread_local char g_err[512] = "";
 
 void pf_set_error(const char* msg) {
@@ -302,6 +306,16 @@ long long pf_partials_count(const pf_problem* p) {
   return (long long)PF_PART_WG + ((long long)p->n_part_blocks + PF_RG) * (long long)p->pad_total + PF_TICKETS;
 }
 
+int pf_fusion_info(const pf_problem* p) {
+  if (check_problem(p) != PF_OK) return PF_ERR_ARG;
+  int m = 0;
+  if (can_fuse_forward(p)) m |= PF_FUSED_FORWARD;
+  if (can_fuse_backward(p)) m |= PF_FUSED_BACKWARD;
+  if (can_fuse_theta_update(p)) m |= PF_FUSED_THETA_UPDATE;
+  if (p->u_alt != nullptr && p->mesh.n_elems >= PF_GRAPH_DAG_MIN_ELEMS) m |= PF_FUSED_U_PINGPONG;
+  return m;
+}
+
 int pf_pack_theta(const pf_problem* p, void* stream) {
   int rc = check_problem(p);
   if (rc) return rc;
@@ -461,7 +475,6 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream) {
 #define PF_CAP_EV 6
 // below this many elements the kernels are too short to hide anything behind: the branches' fork/join cost
 // (~5 us each against ~1.5 us for a plain boundary) would only add to a launch-bound iteration
-#define PF_GRAPH_DAG_MIN_ELEMS 200000   /* measured crossover between 1e5 (chain 0.061 vs DAG 0.067 ms) and 3e5 (0.099 vs 0.092) */
 struct pf_capture {
   hipStream_t s, a, b;
   hipEvent_t* ev;   // PF_CAP_EV per iteration: u readers done | gradu done | theta done | finalize done | forward fork | join

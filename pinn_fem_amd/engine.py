@@ -262,6 +262,10 @@ class HipEngine:
     def _ref(self):
         return C.byref(self.P)
 
+    def fusion_info(self) -> int:
+        """Bit mask of the fused launches of this problem (_capi.PF_FUSED_*)."""
+        return int(self.lib.pf_fusion_info(self._ref()))
+
     # ---- solve_gd support ------------------------------------------------------------------------
     @_on_engine_stream
     def begin(self, u_initial, lam, config, max_iter: Optional[int] = None, want_history=True):

@@ -40,7 +40,7 @@ def main():
     from pinn_fem_amd.cli import generic as g
     rows = []
     for ex in ["example2", "example2-P", "example3", "example3-P", "example4", "example4-P", "example6",
-               "example7", "example7-P"]:
+               "example6-P", "example7", "example7-P"]:
         run = load_run(ex)
         ref = run["result"]
         theta0 = [np.array(t, dtype=np.float32) for t in run["theta0"]]
