@@ -214,7 +214,7 @@ int pf_padded_width(int width);
 int pf_net_pad_count(int in_dim, int width, int n_hidden);
 /* padded-image index (inside the net's image) of the net's `local`-th torch parameter */
 int pf_net_pad_index(int in_dim, int width, int n_hidden, int local);
-/* sizeof of the ABI structs: 0 pf_mesh, 1 pf_net, 2 pf_state, 3 pf_problem (binding self-check) */
+/* sizeof of the ABI structs: 0 pf_mesh, 1 pf_net, 2 pf_state, 3 pf_problem, 4 pf_scalar_id (binding self-check) */
 int pf_sizeof(int what);
 /* floats of operand-image workspace (pf_problem.net_op) one net needs with the MFMA32 engine, or <0 */
 int pf_net_op_count(int in_dim, int width, int n_hidden);
@@ -357,6 +357,31 @@ int pf_pcg_iterations(const pf_problem* p, double* x, double* ws, int n_iter, do
  * state read-back on its own */
 int pf_pcg_graph_create(const pf_problem* p, double* x, double* ws, int n_iter, void* stream, void** graph_out);
 int pf_pcg_state(const pf_problem* p, double* ws, double* state_out, void* stream);
+
+/* ---- scalar (E, A) identification: the device loop of pinn_inverse_problem_gd -------------------------------------
+ * FEM/python/api_pinn_gradient_descent.py:102-121 calls pinn_inverse_problem_gd(nodes, elements, f_ext, fixed_dofs,
+ * young_init, area_init, u_measured, measured_dofs, n_iterations, learning_rate, alpha, beta) — a callee the reference
+ * never defines (ImportError at :19).  The build defines it after the nearest existing code, fem/nn_solver_gd.py:105-125:
+ *   loss = alpha * mean(r_free^2) + beta * mean((u_meas - u[md])^2),   r = c K_1 u - f_ext / (E0 A0),   c = exp(p_E + p_A)
+ * with E = E0 exp(p_E), A = A0 exp(p_A), Adam on u (lr_u = p->lr_u) and on (p_E, p_A) (lr_p), u[fixed] = 0 after the step,
+ * optional box bounds on p.  `p` describes the unit-stiffness problem (both nets disabled, scale 1, measurements in the
+ * mesh, alpha_physics = alpha, alpha_data = beta); K_1 u and its transpose are the node kernels of the GD path.
+ * One iteration = three launches, no host synchronisation: residual + sums, displacement update, scalar update + table. */
+typedef struct pf_scalar_id {
+  float* p;            /* dev [2] log-multipliers (p_E, p_A), updated in place */
+  float* m_p;          /* dev [2] Adam first moments */
+  float* v_p;          /* dev [2] Adam second moments */
+  float* table;        /* dev [n_rows][5] per iteration: loss_total, loss_physics, loss_data, p_E, p_A (after the step) */
+  int32_t n_rows;      /* rows of `table` (iterations beyond are not recorded) */
+  int32_t has_bounds;  /* clamp p to [lo, hi] after the step */
+  float lo[2], hi[2];
+  float inv_ea0;       /* 1 / (E0 * A0): the residual is scaled so that its size does not depend on the units of E */
+  float lr_p;          /* learning rate of (p_E, p_A) */
+  float n_free_f;      /* number of free dofs (denominator of the mean over the residual) */
+  float _pad;
+} pf_scalar_id;
+/* enqueue n_iter iterations (state->iter counts them; pf_reset starts a run) */
+int pf_scalar_gd_iterations(const pf_problem* p, const pf_scalar_id* sp, int n_iter, void* stream);
 
 /* ---- extensions (off the default path) ------------------------------------------------ */
 /* generic Adam (torch.optim.Adam single-tensor arithmetic) on a flat vector */

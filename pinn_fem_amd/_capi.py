@@ -88,6 +88,15 @@ class PfProblem(C.Structure):
     ]
 
 
+class PfScalarId(C.Structure):
+    _fields_ = [
+        ("p", C.c_void_p), ("m_p", C.c_void_p), ("v_p", C.c_void_p), ("table", C.c_void_p),
+        ("n_rows", C.c_int32), ("has_bounds", C.c_int32),
+        ("lo", C.c_float * 2), ("hi", C.c_float * 2),
+        ("inv_ea0", C.c_float), ("lr_p", C.c_float), ("n_free_f", C.c_float), ("_pad", C.c_float),
+    ]
+
+
 # every symbol include/pinnfem_hip.h declares: name -> (restype, argtypes)
 _PP = C.POINTER(PfProblem)
 SYMBOLS = {
@@ -139,6 +148,7 @@ SYMBOLS = {
                                         C.POINTER(C.c_void_p)]),
     "pf_shard_iterations_graph": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_void_p]),
+    "pf_scalar_gd_iterations": (C.c_int, [_PP, C.POINTER(PfScalarId), C.c_int, C.c_void_p]),
     "pf_adam": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pf_diag_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
@@ -187,7 +197,7 @@ def load():
         fn.argtypes = args
     if lib.pf_abi_version() != PF_ABI_VERSION:
         raise PinnFemHipError("libpinnfem_hip.so ABI version mismatch; rebuild the library")
-    for idx, st in enumerate((PfMesh, PfNet, PfState, PfProblem)):
+    for idx, st in enumerate((PfMesh, PfNet, PfState, PfProblem, PfScalarId)):
         if lib.pf_sizeof(idx) != C.sizeof(st):
             raise PinnFemHipError(
                 f"struct layout mismatch for {st.__name__}: C {lib.pf_sizeof(idx)} vs ctypes {C.sizeof(st)}")

@@ -11,6 +11,8 @@ int pf_launch_node_residual(const pf_problem* p, float* f_int_out, int compute_l
 int pf_launch_elem_adjoint(const pf_problem* p, hipStream_t s);
 int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int skip_shared = 0, float* u_out = nullptr);
 int pf_launch_u_home(const pf_problem* p, hipStream_t s);
+int pf_launch_scalar_residual(const pf_problem* p, const pf_scalar_id* sp, hipStream_t s);
+int pf_launch_scalar_update(const pf_problem* p, const pf_scalar_id* sp, hipStream_t s);
 int pf_launch_shard_pack(const pf_problem* p, float* buf2, const float* u2_local, hipStream_t s);
 int pf_launch_shard_update(const pf_problem* p, const float* buf2, float* u2_local, hipStream_t s);
 int pf_launch_shard_flush(const pf_problem* p, const float* u2, hipStream_t s);
@@ -255,6 +257,7 @@ int pf_sizeof(int what) {
     case 1: return (int)sizeof(pf_net);
     case 2: return (int)sizeof(pf_state);
     case 3: return (int)sizeof(pf_problem);
+    case 4: return (int)sizeof(pf_scalar_id);
   }
   return PF_ERR_ARG;
 }
@@ -850,6 +853,22 @@ int pf_shard_flush(const pf_problem* p, const float* u2_reduced, void* stream) {
 
 }  // extern "C"
 extern "C" {
+
+int pf_scalar_gd_iterations(const pf_problem* p, const pf_scalar_id* sp, int n_iter, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!sp || !sp->p || !sp->m_p || !sp->v_p || n_iter < 0 || (sp->n_rows > 0 && !sp->table))
+    return fail(PF_ERR_ARG, "pf_scalar_gd_iterations: bad argument");
+  if (p->net[0].enabled || p->net[1].enabled) return fail(PF_ERR_ARG, "pf_scalar_gd_iterations: scalar materials only");
+  if (!p->m_u || !p->v_u || !(sp->n_free_f > 0.f)) return fail(PF_ERR_ARG, "pf_scalar_gd_iterations: missing state");
+  hipStream_t s = (hipStream_t)stream;
+  for (int i = 0; i < n_iter; ++i) {
+    PF_TRY(pf_launch_scalar_residual(p, sp, s), "scalar_residual");
+    PF_TRY(pf_launch_node_gradu(p, 1, s), "node_gradu");
+    PF_TRY(pf_launch_scalar_update(p, sp, s), "scalar_update");
+  }
+  return PF_OK;
+}
 
 int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step, double lr,
             double beta1, double beta2, double eps, void* stream) {

@@ -543,6 +543,97 @@ __global__ void k_reset(pf_problem P) {
   }
 }
 
+// ---- scalar (E, A) identification (pf_scalar_gd_iterations; include/pinnfem_hip.h) ---------------------------------------
+// residual of the unit-stiffness operator scaled by c = exp(p_E + p_A), its adjoint seed g_f = c g_r, and the block sums
+// the scalar update needs: sum r^2 | sum d^2 | sum g_r (K_1 u)   (slots R2H(0), D2H(0), R2H(1) of the partial sums)
+template <int DIM>
+__global__ __launch_bounds__(PF_NODE_THREADS) void k_scalar_residual(pf_problem P, pf_scalar_id SP) {
+  __shared__ float red[16];
+  const pf_mesh& M = P.mesh;
+  const float c = expf(SP.p[0] + SP.p[1]);
+  const float gcoef = P.alpha_physics * 2.f / SP.n_free_f;          // d(alpha * mean r^2) / dr = gcoef * r
+  float sum_r2 = 0.f, sum_d2 = 0.f, sum_gk = 0.f;
+  for (int node = blockIdx.x * blockDim.x + threadIdx.x; node < M.n_nodes; node += gridDim.x * blockDim.x) {
+    float f[2];
+    gather_kv<DIM>(P, P.u, node, f);
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) {
+      const int dof = node * DIM + k;
+      const unsigned fl = M.dof_flags[dof];
+      float gf = 0.f;
+      if (!(fl & PF_DOF_FIXED)) {
+        const float r = c * f[k] - M.f_ext[dof] * SP.inv_ea0;
+        const float gr = gcoef * r;
+        sum_r2 += r * r;
+        sum_gk += gr * f[k];
+        gf = c * gr;
+      }
+      P.g_f[dof] = gf;
+      if (P.use_data && (fl & PF_DOF_MEASURED)) {
+        const float d = M.meas_val[dof] - P.u[dof];
+        sum_d2 += d * d;
+      }
+    }
+  }
+  const float t0 = pf_block_sum(sum_r2, red);
+  const float t1 = pf_block_sum(sum_d2, red);
+  const float t2 = pf_block_sum(sum_gk, red);
+  if (threadIdx.x == 0) {
+    P.partials[PF_PART_R2H(0) + blockIdx.x] = t0;
+    P.partials[PF_PART_D2H(0) + blockIdx.x] = t1;
+    P.partials[PF_PART_R2H(1) + blockIdx.x] = t2;
+  }
+}
+
+// one block: losses, d loss / d(p_E + p_A), Adam on (p_E, p_A) (torch single-tensor arithmetic), bounds, table row, the
+// next step's Adam scalars of the displacement update
+__global__ __launch_bounds__(256) void k_scalar_update(pf_problem P, pf_scalar_id SP, int nb_node) {
+  PF_NO_CONTRACT
+  __shared__ double dred[16];
+  pf_state* S = P.state;
+  const int it = S->iter;
+  const float c = expf(SP.p[0] + SP.p[1]);
+  double a = 0.0, b = 0.0, g = 0.0;
+  for (int i = threadIdx.x; i < nb_node; i += blockDim.x) {
+    a += (double)P.partials[PF_PART_R2H(0) + i];
+    b += (double)P.partials[PF_PART_D2H(0) + i];
+    g += (double)P.partials[PF_PART_R2H(1) + i];
+  }
+  const float sum_r2 = (float)pf_block_sum_d(a, dred);
+  const float sum_d2 = (float)pf_block_sum_d(b, dred);
+  const float sum_gk = (float)pf_block_sum_d(g, dred);
+  if (threadIdx.x != 0) return;
+  const float loss_p = sum_r2 / SP.n_free_f;
+  const float loss_d = P.use_data ? sum_d2 / P.n_meas_f : 0.f;
+  const float loss = P.alpha_physics * loss_p + P.alpha_data * loss_d;
+  const float g_c = sum_gk * c;                                     // the same gradient for p_E and p_A
+  const double t = (double)(it + 1);
+  const double bc1 = 1.0 - pow(P.beta1, t), bc2 = 1.0 - pow(P.beta2, t);
+  const float step_size = (float)((double)SP.lr_p / bc1), bc2s = (float)sqrt(bc2);
+  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2), eps = (float)P.eps;
+  float pn[2];
+  for (int k = 0; k < 2; ++k) {
+    float m = SP.m_p[k], v = SP.v_p[k], x = SP.p[k];
+    m = m + b1w * (g_c - m);
+    v = v * b2;
+    v = v + (b2w * g_c) * g_c;
+    const float denom = sqrtf(v) / bc2s + eps;
+    x = x + (-step_size) * (m / denom);
+    if (SP.has_bounds) x = fminf(fmaxf(x, SP.lo[k]), SP.hi[k]);
+    SP.m_p[k] = m; SP.v_p[k] = v; SP.p[k] = x;
+    pn[k] = x;
+  }
+  if (it < SP.n_rows) {
+    float* row = SP.table + (size_t)it * 5;
+    row[0] = loss; row[1] = loss_p; row[2] = loss_d; row[3] = pn[0]; row[4] = pn[1];
+  }
+  S->loss_total = loss; S->loss_physics = loss_p; S->loss_data = loss_d; S->residual_norm = sqrtf(sum_r2);
+  S->iter = it + 1;
+  const double t2 = (double)(it + 2);
+  S->step_size_u = (float)((double)P.lr_u / (1.0 - pow(P.beta1, t2)));
+  S->bc2_sqrt = (float)sqrt(1.0 - pow(P.beta2, t2));
+}
+
 // ---- generic Adam ------------------------------------------------------------------------------
 __global__ void k_adam(float* p, const float* g, float* m, float* v, int n, float step_size,
                        float bc2s, float b1w, float b2, float b2w, float eps) {
@@ -738,6 +829,17 @@ int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s) {
 int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s) {
   if (p->mesh.dim == 2) hipLaunchKernelGGL(k_dense_k<2>, dim3(1), dim3(64), 0, s, *p, K);
   else hipLaunchKernelGGL(k_dense_k<1>, dim3(1), dim3(64), 0, s, *p, K);
+  return PF_CHECK_LAUNCH();
+}
+
+int pf_launch_scalar_residual(const pf_problem* p, const pf_scalar_id* sp, hipStream_t s) {
+  const int nb = pf_node_blocks(p->mesh.n_nodes);
+  if (p->mesh.dim == 2) hipLaunchKernelGGL(k_scalar_residual<2>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, *sp);
+  else hipLaunchKernelGGL(k_scalar_residual<1>, dim3(nb), dim3(PF_NODE_THREADS), 0, s, *p, *sp);
+  return PF_CHECK_LAUNCH();
+}
+int pf_launch_scalar_update(const pf_problem* p, const pf_scalar_id* sp, hipStream_t s) {
+  hipLaunchKernelGGL(k_scalar_update, dim3(1), dim3(256), 0, s, *p, *sp, pf_node_blocks(p->mesh.n_nodes));
   return PF_CHECK_LAUNCH();
 }
 

@@ -152,13 +152,10 @@ def test_whole_example_runs(ex, monkeypatch):
     ref = run["result"]
     ref_counts = _leaf_counts(run)
     assert out["converged"] == ref["converged"]
-    # Every solve_gd call stops at EXACTLY the reference's iteration (measured on all ten examples, 1283-4942
-    # iterations per run; profiles/r02_parity_summary.json).  The stop test compares a float32 monitor with 1e-6, so a
-    # crossing that falls within round-off of the tolerance may move by one iteration: +-1 per call is the bound, and
-    # the run total must agree within 2.
-    assert len(counts) == len(ref_counts)
-    assert all(abs(a - b) <= 1 for a, b in zip(counts, ref_counts)), (counts, ref_counts)
-    assert abs(sum(counts) - sum(ref_counts)) <= 2, (sum(counts), sum(ref_counts))
+    # Every solve_gd call stops at EXACTLY the reference's iteration: measured on all ten examples (1283-4942 iterations
+    # per run, 10-20 calls each; profiles/r03_parity_summary.json) and asserted as such — the device arithmetic is
+    # deterministic (fixed-order sums, no float atomics), so a one-iteration drift would be a change of the arithmetic.
+    assert counts == ref_counts, (counts, ref_counts)
     assert rel_err(out["displacements"], ref["displacements"]) < 1e-5
     assert np.max(np.abs(np.array(out["reactions"]) - np.array(ref["reactions"]))) < 1e-5
     if "identified_properties" in ref:
