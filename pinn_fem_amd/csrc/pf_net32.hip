@@ -44,6 +44,15 @@
 #ifndef PF_N32_DBG_ENABLE
 #define PF_N32_DBG_ENABLE 0
 #endif
+// Experiment knobs of the backward's block shape (build-time; pinn_fem_amd/build.py: PINNFEM_BW2_NOPAIR=1 sets them for the
+// fused two-net translation units): PF_BW_PAIR 0 = recompute tile by tile (fewer registers, see bw_pair),
+// PF_BW_MAX_THREADS = cap on the block size.
+#ifndef PF_BW_PAIR
+#define PF_BW_PAIR 1
+#endif
+#ifndef PF_BW_MAX_THREADS
+#define PF_BW_MAX_THREADS 1024
+#endif
 #define PF_CAT2(a, b) a##b
 #define PF_CAT(a, b) PF_CAT2(a, b)
 
@@ -493,11 +502,12 @@ struct Eng {
   // -> MFMA dependency chain better than a third wave does.  Used where it compiles without spills (ScratchSize 0 in
   // every bucket): two hidden layers, or three with PF_NR <= 8; one hidden layer keeps the per-tile form at 16 waves.
   template <int L>
-  static constexpr bool bw_pair() { return L == 2 || (L == 3 && NR <= 8); }
+  static constexpr bool bw_pair() { return PF_BW_PAIR && (L == 2 || (L == 3 && NR <= 8)); }
   template <int L, bool GEA>
   static constexpr int bw_threads() {
     if (bw_pair<L>()) return 512;
-    return !COMPACT ? 512 : (L == 1 ? 1024 : (L == 2 && !(GEA && NR > 10) ? 768 : 512));
+    constexpr int t = !COMPACT ? 512 : (L == 1 ? 1024 : (L == 2 && !(GEA && NR > 10) ? 768 : 512));
+    return t < PF_BW_MAX_THREADS ? t : PF_BW_MAX_THREADS;
   }
 
   // lane's pairs (hi or lo) of registers 0..15 -> split `sp` of the region at byte offset `reg` of the wave scratch.
