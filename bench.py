@@ -244,7 +244,7 @@ def launch_workers(n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--elems", type=int, default=1_000_000, help="elements per GPU")
     ap.add_argument("--workload", default="ex4", choices=["ex4", "ex3"])

@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256) void k_u_home(pf_problem P) {
 }
 int pf_launch_u_home(const pf_problem* p, hipStream_t s) {
   int nb = (p->mesh.n_dofs + 255) / 256;
-  if (nb > 2048) nb = 2048;
+  if (nb > 64) nb = 64;       // it copies only after a stop in mid-replay; in every other replay it should cost nothing
   hipLaunchKernelGGL(k_u_home, dim3(nb), dim3(256), 0, s, *p);
   return PF_CHECK_LAUNCH();
 }

@@ -180,6 +180,8 @@ class HipEngine:
         self.P = PfProblem()
         self._graph = None
         self._configured = False
+        env_k = os.environ.get("PINNFEM_GRAPH_ITERS")
+        self.GRAPH_ITERS = int(env_k) if env_k else (self.GRAPH_ITERS_LARGE if hp.n_elems >= 200_000 else self.GRAPH_ITERS)
         self.configure(lam=1.0)
 
     # ------------------------------------------------------------------------------------------
@@ -288,7 +290,12 @@ class HipEngine:
         _capi.check(self.lib.pf_reset(self._ref(), s), "pf_reset")
         _capi.check(self.lib.pf_pack_theta(self._ref(), s), "pf_pack_theta")
 
-    GRAPH_ITERS = int(os.environ.get("PINNFEM_GRAPH_ITERS", 10))   # iterations per captured hipGraph
+    # iterations per captured hipGraph.  A replay ends with ~25 us of stand-alone kernels (parameter update, finalize) that the
+    # iterations inside it do not pay, so large meshes replay 20 at a time (the host polls the stop flag every 50
+    # anyway); small meshes keep 10 (a graph is captured per solve_gd call: capture time counts there).
+    # PINNFEM_GRAPH_ITERS overrides both (even numbers: the graph ping-pongs state between two halves).
+    GRAPH_ITERS = 10
+    GRAPH_ITERS_LARGE = 20
 
     def _drop_graph(self):
         g = getattr(self, "_graph", None)

@@ -175,8 +175,10 @@ def solve_gd(
     eng.begin(u_initial, target_load_factor, config)
     n_done = 0
     st = None
+    k = max(int(eng.GRAPH_ITERS), 1)
+    poll = max(k, (CHECK_EVERY // k) * k)      # whole graph replays per poll (large meshes replay 20 iterations at a time)
     while n_done < config.max_iterations:
-        chunk = min(CHECK_EVERY, config.max_iterations - n_done)
+        chunk = min(poll, config.max_iterations - n_done)
         eng.iterate(chunk)
         st = eng.state()                       # one small D2H copy + sync per chunk
         n_done = st.iter

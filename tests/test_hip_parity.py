@@ -952,6 +952,35 @@ def test_full_size_graph_equals_eager_bitwise():
     assert np.all(np.isfinite(outs[0][2])) and outs[0][2][-1, 0] < outs[0][2][0, 0]      # and the loss went down
 
 
+@pytest.mark.parametrize("max_it,tol,expect", [(40, 1e30, 12), (13, 0.0, 13), (15, 0.0, 15)])
+def test_graph_stop_in_mid_replay_equals_eager(max_it, tol, expect):
+    """The iteration graph ping-pongs the displacement vector and the parameter state between two halves; a stop raised
+    INSIDE a replay (stop test at iteration 12; max_iterations 13 and 15: odd counts, so the live halves are the
+    alternates) must still leave u, theta, the Adam moments and the history where and what the eager launches leave.
+    250000 elements: the dependency-DAG form of the graph (>= 2*10^5 elements)."""
+    from bench import build_model
+    from pinn_fem_amd.engine import HipEngine
+    from pinn_fem_amd.fem.solver import SolverConfig
+    outs = []
+    for use_graph in (True, False):
+        model, mv, md, _ = build_model(250_000, "ex4")
+        cfg = SolverConfig(max_iterations=max_it, tolerance=tol, learning_rate_u=0.01, learning_rate_theta=5e-4)
+        eng = HipEngine(model, mv, md)
+        assert eng.fusion_info() == 15                     # every fused form is active on this problem
+        eng.begin(None, 0.1, cfg, want_history=True)
+        eng.iterate(2 * eng.GRAPH_ITERS, use_graph=use_graph)
+        torch.cuda.synchronize()
+        st = eng.state()
+        assert st.iter == expect and st.done == 1 and st.theta_half == 0
+        outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.m_t.cpu().numpy().copy(),
+                     eng.v_t.cpu().numpy().copy(), eng.m_u.cpu().numpy().copy(), eng.history(expect).copy()))
+        # the nets' operand images belong to the final theta: a property evaluation from the stored images (no re-pack)
+        # equals one after re-packing
+        del eng
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+
+
 def test_full_size_loss_and_grads_vs_oracle_prefix():
     """pf_loss_and_grads at 10^6 elements (ex4 shape): f_int, grad_u and the residual-driven element adjoint on the
     first 5000 elements equal the oracle's on that prefix (interior nodes; the prefix's last node sees one element
@@ -1113,8 +1142,8 @@ def test_large_load_factor_gradients_vs_oracle(lam):
 
 def test_beyond_infinity_cache_1e7_elements():
     """10^7 elements (working set ~1.2 GB, far beyond the 256 MiB Infinity Cache), example4 shape,
-    default engine and formulation: (1) sum f_int = 0 (self-equilibrated element forces); (2) ten iterations replayed as
-    the hipGraph == the same ten launched eagerly, bit for bit; (3) loss terms / grad_u on the first 5000 elements'
+    default engine and formulation: (1) sum f_int = 0 (self-equilibrated element forces); (2) one replay of the iteration
+    hipGraph (20 iterations) == the same iterations launched eagerly, bit for bit; (3) loss terms / grad_u on the first 5000 elements'
     interior dofs against the oracle on that prefix (delta formulation on both sides: |u| reaches 10^4 on this bar)."""
     from bench import build_model
     from pinn_fem_amd.engine import HipEngine
@@ -1122,7 +1151,7 @@ def test_beyond_infinity_cache_1e7_elements():
     n, m = 10_000_000, 5000
     model, mv, md, _ = build_model(n, "ex4")
     theta0 = [p.detach().cpu().numpy().copy() for p in model.material.get_all_torch_params()]
-    cfg = SolverConfig(max_iterations=12, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
+    cfg = SolverConfig(max_iterations=24, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
     eng = HipEngine(model, mv, md)
     outs = []
     for use_graph in (True, False):
@@ -1130,10 +1159,10 @@ def test_beyond_infinity_cache_1e7_elements():
             for p, a in zip(model.material.get_all_torch_params(), theta0):
                 p.copy_(torch.from_numpy(a).to(p.device))
         eng.begin(None, 0.1, cfg, want_history=True)
-        eng.iterate(10, use_graph=use_graph)
+        eng.iterate(eng.GRAPH_ITERS, use_graph=use_graph)       # one whole replay
         torch.cuda.synchronize()
-        assert eng.state().iter == 10
-        outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.history(10).copy()))
+        assert eng.state().iter == eng.GRAPH_ITERS
+        outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.history(eng.GRAPH_ITERS).copy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert np.array_equal(outs[0][2], outs[1][2]) and np.all(np.isfinite(outs[0][2]))
     # (1) equilibrium of the element forces at a smooth displacement field
