@@ -391,6 +391,10 @@ int pf_adam(float* param, const float* grad, float* m, float* v, int n, int step
  * no such preconditioner (solver.py:113-195 is a two-phase schedule), so nothing calls this
  * by default.  Uses p->prop_e/prop_a from the last pf_net_forward. */
 int pf_diag_k(const pf_problem* p, float* diag_out, void* stream);
+/* k_global in coordinate format for meshes of any size (SURVEY 7.1b `assemble_coo`): the (2*dim)^2 entries
+ * `k_global[g, h] += ke[a, b]` of every element (nn_assembly.py:228-229) as triplets, element after element; rows_out /
+ * cols_out dev int64 [n_elems*(2*dim)^2], vals_out dev float32; duplicates are summed by the consumer (coalesce). */
+int pf_coo_k(const pf_problem* p, long long* rows_out, long long* cols_out, float* vals_out, void* stream);
 /* dense k_global [n_dofs][n_dofs] row-major, for assemble_system_torch's return value
  * (nn_assembly.py:228-231); small n_dofs only (<= 4096). */
 int pf_dense_k(const pf_problem* p, float* k_out, void* stream);

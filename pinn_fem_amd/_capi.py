@@ -153,6 +153,7 @@ SYMBOLS = {
                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "pf_diag_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
     "pf_dense_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
+    "pf_coo_k": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 

@@ -26,6 +26,7 @@ int pf_launch_adam(float* param, const float* grad, float* m, float* v, int n, i
                    double beta1, double beta2, double eps, hipStream_t s);
 int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s);
 int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s);
+int pf_launch_coo_k(const pf_problem* p, long long* rows, long long* cols, float* vals, hipStream_t s);
 
 // below this many elements the iteration graph is a plain chain: the kernels are then too short to hide anything behind,
 // the branches' fork/join cost (~5 us each against ~1.5 us for a plain boundary) would only add to a launch-bound iteration
@@ -882,6 +883,14 @@ int pf_diag_k(const pf_problem* p, float* diag_out, void* stream) {
   if (rc) return rc;
   if (!diag_out) return fail(PF_ERR_ARG, "null diag_out");
   PF_TRY(pf_launch_diag_k(p, diag_out, (hipStream_t)stream), "pf_diag_k");
+  return PF_OK;
+}
+
+int pf_coo_k(const pf_problem* p, long long* rows_out, long long* cols_out, float* vals_out, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  if (!rows_out || !cols_out || !vals_out) return fail(PF_ERR_ARG, "null COO output");
+  PF_TRY(pf_launch_coo_k(p, rows_out, cols_out, vals_out, (hipStream_t)stream), "pf_coo_k");
   return PF_OK;
 }
 

@@ -699,6 +699,41 @@ __global__ void k_dense_k(pf_problem P, float* K) {
   }
 }
 
+// k_global in coordinate format (the reference's 16 `k_global[g, h] += ke[a, b]` per element, nn_assembly.py:228-229, kept
+// as triplets instead of summed into a dense matrix): entry t of element e at e*(2*DIM)^2 + t, rows / cols int64 like
+// torch.sparse_coo_tensor wants them; duplicates (shared nodes) are summed by the consumer (coalesce).
+template <int DIM>
+__global__ __launch_bounds__(256) void k_coo_k(pf_problem P, long long* __restrict__ rows, long long* __restrict__ cols,
+                                               float* __restrict__ vals) {
+  const pf_mesh& M = P.mesh;
+  constexpr int nd = 2 * DIM;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < M.n_elems; e += gridDim.x * blockDim.x) {
+    const int2 nn = reinterpret_cast<const int2*>(M.conn)[e];
+    const ElemK k = load_k<DIM>(P, e);
+    const size_t base = (size_t)e * nd * nd;
+#pragma unroll
+    for (int a = 0; a < nd; ++a)
+#pragma unroll
+      for (int b = 0; b < nd; ++b) {
+        int da, db;
+        float pat;
+        if (DIM == 2) {
+          da = (a < 2 ? nn.x : nn.y) * 2 + (a & 1);
+          db = (b < 2 ? nn.x : nn.y) * 2 + (b & 1);
+          const float v = ((a & 1) == 0 && (b & 1) == 0) ? k.c2 : (((a & 1) && (b & 1)) ? k.s2 : k.cs);
+          pat = ((a < 2) == (b < 2)) ? v : -v;
+        } else {
+          da = a == 0 ? nn.x : nn.y;
+          db = b == 0 ? nn.x : nn.y;
+          pat = a == b ? k.c2 : -k.c2;
+        }
+        rows[base + a * nd + b] = da;
+        cols[base + a * nd + b] = db;
+        vals[base + a * nd + b] = pat;
+      }
+  }
+}
+
 }  // namespace
 
 // ---- host launchers (called from pf_api.hip) ---------------------------------------------------
@@ -829,6 +864,15 @@ int pf_launch_diag_k(const pf_problem* p, float* diag, hipStream_t s) {
 int pf_launch_dense_k(const pf_problem* p, float* K, hipStream_t s) {
   if (p->mesh.dim == 2) hipLaunchKernelGGL(k_dense_k<2>, dim3(1), dim3(64), 0, s, *p, K);
   else hipLaunchKernelGGL(k_dense_k<1>, dim3(1), dim3(64), 0, s, *p, K);
+  return PF_CHECK_LAUNCH();
+}
+
+int pf_launch_coo_k(const pf_problem* p, long long* rows, long long* cols, float* vals, hipStream_t s) {
+  int nb = (p->mesh.n_elems + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  if (p->mesh.dim == 2) hipLaunchKernelGGL(k_coo_k<2>, dim3(nb), dim3(256), 0, s, *p, rows, cols, vals);
+  else hipLaunchKernelGGL(k_coo_k<1>, dim3(nb), dim3(256), 0, s, *p, rows, cols, vals);
   return PF_CHECK_LAUNCH();
 }
 

@@ -488,6 +488,19 @@ class HipEngine:
         return out
 
     @_on_engine_stream
+    def sparse_k(self, lam: Optional[float] = None) -> torch.Tensor:
+        """k_global as a coalesced torch sparse COO tensor (any mesh size; pf_coo_k)."""
+        self.eval_properties(lam)
+        n, nd = self.plan.n_dofs, 2 * self.plan.dim
+        nnz = max(self.plan.n_elems, 0) * nd * nd
+        idx = torch.empty((2, max(nnz, 1)), dtype=torch.int64, device=self.device)
+        vals = torch.empty(max(nnz, 1), dtype=torch.float32, device=self.device)
+        if nnz:
+            _capi.check(self.lib.pf_coo_k(self._ref(), idx[0].data_ptr(), idx[1].data_ptr(), vals.data_ptr(), self._stream()),
+                        "pf_coo_k")
+        return torch.sparse_coo_tensor(idx[:, :nnz], vals[:nnz], (n, n)).coalesce()
+
+    @_on_engine_stream
     def dense_k(self, lam: Optional[float] = None) -> torch.Tensor:
         self.eval_properties(lam)
         n = self.plan.n_dofs

@@ -40,6 +40,11 @@ class LazyStiffness:
     def to_dense(self) -> torch.Tensor:
         return self.engine.dense_k(self.load_factor)
 
+    def to_sparse(self) -> torch.Tensor:
+        """k_global as a coalesced sparse COO tensor: the reference's dense matrix (nn_assembly.py:228-231) in the
+        only form that exists at scale."""
+        return self.engine.sparse_k(self.load_factor)
+
 
 def _engine(model: FEMModel) -> HipEngine:
     eng = getattr(model, "_pf_assembly_engine", None)
