@@ -42,6 +42,8 @@ def _sources():
     n32 = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
     if os.environ.get("PINNFEM_N32_DBG", "0") == "1":       # timing-experiment build: the PF_N32_DBG knobs are live
         n32.append("-DPF_N32_DBG_ENABLE=1")
+    if os.environ.get("PINNFEM_N32_NOPIPE", "0") == "1":    # experiment build: hidden layers as [all MFMAs][all tanh stages]
+        n32.append("-DPF_N32_PIPE=0")
     units += [(f"pf_net32_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}"] + n32) for r in reversed(NR_BUCKETS)]
     units += [(f"pf_net32b_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}", "-DPF_PREC=1"] + n32) for r in reversed(NR_BUCKETS)]
     # the fused two-net kernels (E net of bucket r, A net of any bucket): translation units of their own

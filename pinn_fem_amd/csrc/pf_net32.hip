@@ -47,6 +47,11 @@
 // Experiment knobs of the backward's block shape (build-time; pinn_fem_amd/build.py: PINNFEM_BW2_NOPAIR=1 sets them for the
 // fused two-net translation units): PF_BW_PAIR 0 = recompute tile by tile (fewer registers, see bw_pair),
 // PF_BW_MAX_THREADS = cap on the block size.
+// PF_N32_PIPE 1: in the two-tile hidden layer, tile 1's matrix products carry tile 0's first tanh stage in their gaps
+// (MI355X_MICROARCH.md / tools/pipe_probe.hip: an MFMA gap hides 24 cycles of vector issue): same values, other order.
+#ifndef PF_N32_PIPE
+#define PF_N32_PIPE 1
+#endif
 #ifndef PF_BW_PAIR
 #define PF_BW_PAIR 1
 #endif
@@ -109,6 +114,15 @@ __device__ __forceinline__ f32x16 mfma3(f32x16 acc, h8 ahi, h8 alo, h8 bhi, h8 b
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
   return acc;
+}
+
+// the K-th of the (up to) three products of mfma3, on its own (the pipelined hidden layer places vector work between them)
+template <int K>
+__device__ __forceinline__ f32x16 mfma3_part(f32x16 acc, h8 ahi, h8 alo, h8 bhi, h8 blo) {
+  if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, ahi), __builtin_bit_cast(bf8, bhi), acc, 0, 0, 0);
+  if constexpr (K == 0) return __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, bhi, acc, 0, 0, 0);
+  if constexpr (K == 1) return __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, blo, acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, bhi, acc, 0, 0, 0);
 }
 
 // v_permlane32_swap_b32 vdst, src: lanes 32-63 of vdst swap with lanes 0-31 of src.  Inline asm: the clang
@@ -323,6 +337,48 @@ struct Eng {
     PF_STAGE();
   }
 
+  // The same activation when tile 0's first stage (e0 = exp2(z0 cz)) has already been issued between tile 1's matrix
+  // products: the stages of the two tiles are staggered by one, every stage still holds ~2 NR independent instructions.
+  template <int L, bool BWD, int LL>
+  static __device__ __forceinline__ void activate2_staggered(TileAct<L, BWD>& A0, TileAct<L, BWD>& A1, float (&e0)[NR],
+                                                             const float (&z1)[NR], float cz) {
+    float e1[NR];
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      e1[R] = __builtin_amdgcn_exp2f(z1[R] * cz);
+      e0[R] = __builtin_amdgcn_rcpf(e0[R] + 1.0f);
+    });
+    PF_STAGE();
+    float a0[2 * NPR], a1[2 * NPR];
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      e1[R] = __builtin_amdgcn_rcpf(e1[R] + 1.0f);
+      a0[R] = fmaf(-2.0f * PF_N32_KA, e0[R], PF_N32_KA);
+      if constexpr (BWD) A0.t[LL - 1][R] = fmaf(-e0[R], e0[R], e0[R]);
+      if constexpr (LL == L) A0.aL[R] = a0[R];
+    });
+    if constexpr (NR & 1) { a0[NR] = 0.f; a1[NR] = 0.f; }
+    PF_STAGE();
+    sfor<0, NR>([&](auto r) {
+      constexpr int R = r;
+      a1[R] = fmaf(-2.0f * PF_N32_KA, e1[R], PF_N32_KA);
+      if constexpr (BWD) A1.t[LL - 1][R] = fmaf(-e1[R], e1[R], e1[R]);
+      if constexpr (LL == L) A1.aL[R] = a1[R];
+    });
+    sfor<0, NPK>([&](auto q) {
+      constexpr int Q = q;
+      if constexpr (Q < NPR) split_pair(a0[2 * Q], a0[2 * Q + 1], A0.hi[LL - 1][Q], A0.lo[LL - 1][Q]);
+      else { A0.hi[LL - 1][Q] = 0u; A0.lo[LL - 1][Q] = 0u; }
+    });
+    PF_STAGE();
+    sfor<0, NPK>([&](auto q) {
+      constexpr int Q = q;
+      if constexpr (Q < NPR) split_pair(a1[2 * Q], a1[2 * Q + 1], A1.hi[LL - 1][Q], A1.lo[LL - 1][Q]);
+      else { A1.hi[LL - 1][Q] = 0u; A1.lo[LL - 1][Q] = 0u; }
+    });
+    PF_STAGE();
+  }
+
   // weights of one hidden layer as a wave reads them from the LDS image: bias vector (initial accumulator) and the
   // split A operands of both k-steps.  Loaded one phase AHEAD of their use (before the tanh stages of the previous
   // layer), so that the LDS latency hides behind the transcendentals instead of stalling the matrix products.
@@ -383,6 +439,41 @@ struct Eng {
       constexpr int LL = l;
       const LayerW& w = wl[LL - 2];
       f32x16 acc0 = bias_acc(w), acc1 = acc0;
+      constexpr float CZ = C2 / (PF_N32_KA * PF_N32_KW);
+      if constexpr (PF_N32_PIPE && !PF_N32_DBG_ENABLE) {
+        // tile 0's products, then tile 1's with tile 0's mul + exp2 stage spread over their gaps (each gap: <= PER
+        // registers = PER x (4 + 8) cycles of issue against the 24 a gap hides); sched_barriers pin the order
+        sfor<0, KS>([&](auto s) {
+          constexpr int S = s;
+          acc0 = mfma3(acc0, w.ahi[S], w.alo[S],
+                       as_h8(A0.hi[LL - 2][4 * S], A0.hi[LL - 2][4 * S + 1], A0.hi[LL - 2][4 * S + 2], A0.hi[LL - 2][4 * S + 3]),
+                       as_h8(A0.lo[LL - 2][4 * S], A0.lo[LL - 2][4 * S + 1], A0.lo[LL - 2][4 * S + 2], A0.lo[LL - 2][4 * S + 3]));
+        });
+        if constexpr (LL < L) load_layer<LL + 1, false>(img, lane, wl[LL - 1]);
+        else load_wo(img, lane, wv);
+        constexpr int NP = BF ? 1 : 3;                 // products per k-step
+        constexpr int NM = NP * KS;                    // matrix instructions of tile 1
+        constexpr int PER = (NR + NM - 1) / NM;        // tile-0 registers per gap
+        float e0[NR];
+        PF_STAGE();
+        sfor<0, NM>([&](auto m) {
+          constexpr int M = m, S = M / NP, K = BF ? 2 : M % NP;
+          acc1 = mfma3_part<K>(acc1, w.ahi[S], w.alo[S],
+                               as_h8(A1.hi[LL - 2][4 * S], A1.hi[LL - 2][4 * S + 1], A1.hi[LL - 2][4 * S + 2], A1.hi[LL - 2][4 * S + 3]),
+                               as_h8(A1.lo[LL - 2][4 * S], A1.lo[LL - 2][4 * S + 1], A1.lo[LL - 2][4 * S + 2], A1.lo[LL - 2][4 * S + 3]));
+          sfor<M * PER, (M + 1) * PER < NR ? (M + 1) * PER : NR>([&](auto r) {
+            constexpr int R = r;
+            e0[R] = __builtin_amdgcn_exp2f(acc0[R] * CZ);
+            // (an empty volatile use: without it the compiler sinks the stage below a later branch — the lockstep barrier of
+            //  the forward kernels — and the gap stays empty)
+            asm volatile("" : "+v"(e0[R]));
+          });
+          PF_STAGE();
+        });
+        float z1[NR];
+        sfor<0, NR>([&](auto r) { constexpr int R = r; z1[R] = acc1[R]; });
+        activate2_staggered<L, BWD, LL>(A0, A1, e0, z1, CZ);
+      } else {
       if (!(dbg & 8)) {
         sfor<0, KS>([&](auto s) {
           constexpr int S = s;
@@ -402,7 +493,8 @@ struct Eng {
       else load_wo(img, lane, wv);
       float z0[NR], z1[NR];
       sfor<0, NR>([&](auto r) { constexpr int R = r; z0[R] = acc0[R]; z1[R] = acc1[R]; });
-      activate2<L, BWD, LL>(A0, A1, z0, z1, C2 / (PF_N32_KA * PF_N32_KW), dbg);
+      activate2<L, BWD, LL>(A0, A1, z0, z1, CZ, dbg);
+      }
     });
     if (grp == 2) __builtin_amdgcn_s_barrier();
     p0 = 0.f;
@@ -882,11 +974,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
 
 // GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the other net's
 // backward.  Partial gradient row of the block: the padded image of pf_common.h (what theta_stage1 sums).
-// Stores of a block's partial gradient row: agent-scope write-through (global_store ... sc1).  The fused backward launch
-// hands the rows to the LAST block of each row group inside the launch (rows_reduce_last below), and a hand-off without a
+// Stores of a block's partial gradient row; wt: agent-scope write-through (global_store ... sc1).  With PF_FUSE_S1=1 the
+// fused backward launch hands the rows to the LAST block of each row group inside the launch (rows_reduce_last below), and a hand-off without a
 // release fence needs every handed-off byte stored this way (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms).
-__device__ __forceinline__ void row_store(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void row_store(float* p, float v, bool wt) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;                                       // (the usual case: the rows are read by the NEXT launch)
 }
 __device__ __forceinline__ float row_load(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -932,7 +1025,7 @@ __device__ __forceinline__ void rows_reduce_last(const pf_problem& P, int nb_row
 // caller places a block barrier between two phases that share cst / wscr.
 template <int NR, int L, int IN, bool GEA>
 __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, int hp, int dbg, const unsigned char* smem,
-                                               unsigned char* cst, unsigned char* wscr) {
+                                               unsigned char* cst, unsigned char* wscr, bool wt = false) {
   using E = Eng<NR>;
   constexpr int CONST_BYTES = E::CONST_BYTES, WAVE_SCRATCH = E::WAVE_SCRATCH, REGION = E::REGION, NPK = E::NPK;
   constexpr bool COMPACT = E::COMPACT;
@@ -1078,7 +1171,7 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
   const int W = net.width;
   float* __restrict__ prow = P.partials + PF_PART_WG + (size_t)blockIdx.x * P.pad_total + net.pad_off;
   const int padc = pf_pad_count(hp, L);
-  for (int i = threadIdx.x; i < padc; i += blockDim.x) row_store(prow + i, 0.f);
+  for (int i = threadIdx.x; i < padc; i += blockDim.x) row_store(prow + i, 0.f, wt);
   // scale of d_l relative to the true gradient after the 1/S: 4^(L-l)
   sfor<0, L>([&](auto l) {
     constexpr int LL = l + 1;                      // layer whose weight gradient tile T[LL-1] holds
@@ -1109,7 +1202,7 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
         if (c < IN) { dst = j * 4 + c; k *= c == 0 ? kl : kx; }
         else if (c == IN) dst = j * 4 + IN;                                           // bias (input 1.0)
       }
-      if (dst >= 0) row_store(prow + dst, t / k);
+      if (dst >= 0) row_store(prow + dst, t / k, wt);
     }
   });
   // output unit row: sum over the 32 columns of each half-wave, then over the waves
@@ -1131,13 +1224,13 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
     if (r < NR && u < W) {
       float t = 0.f;
       for (int q = 0; q < waves; ++q) t += stage[q * 64 + hh * 16 + r];
-      row_store(prow + pf_pad_wo(hp, L) + u, t * (1.0f / PF_N32_KA));
+      row_store(prow + pf_pad_wo(hp, L) + u, t * (1.0f / PF_N32_KA), wt);
     }
   }
   if (threadIdx.x == 32) {
     float t = 0.f;
     for (int q = 0; q < waves; ++q) t += stage[waves * 64 + q];
-    row_store(prow + pf_pad_wo(hp, L) + hp, t);
+    row_store(prow + pf_pad_wo(hp, L) + hp, t, wt);
   }
 }
 
@@ -1189,9 +1282,9 @@ __global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_back
   if (s_done != 0 || P.mesh.n_elems <= 0) return;
   unsigned char* cst = smem + 2 * IMGPAD;
   unsigned char* wscr = cst + bw2_const_bytes<NRE, NRA>();
-  backward_phase<NRE, L, IN, true>(P, 0, hp_e, dbg, smem, cst, wscr);
+  backward_phase<NRE, L, IN, true>(P, 0, hp_e, dbg, smem, cst, wscr, reduce_rows != 0);
   __syncthreads();                               // the write-out staging of phase 1 is read; scratch and constants are re-initialised
-  backward_phase<NRA, L, IN, false>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr);
+  backward_phase<NRA, L, IN, false>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr, reduce_rows != 0);
   // reduce_rows: the launch is also theta stage 1 (the last block of every row group sums the group's rows)
   if (reduce_rows) rows_reduce_last(P, (int)gridDim.x);
 }
