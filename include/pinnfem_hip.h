@@ -236,6 +236,11 @@ int pf_pack_theta(const pf_problem* p, void* stream);
 /* NNProperty.value for every element: properties.py:116-161 + generic.py:141 (batch of n_elems
  * instead of n_elems batch-1 calls).  which: 0 young, 1 area.  Output p->prop_e / prop_a. */
 int pf_net_forward(const pf_problem* p, int which, void* stream);
+/* the forward pass of EVERY enabled net (one launch where pf_fusion_info says so) incl. the stiffness records, and the
+ * backward pass of every enabled net with the element adjoint (one two-phase launch where fused; else adjoint + one
+ * launch per net): what one GD iteration enqueues for these two steps.  Idempotent: may be repeated for timing. */
+int pf_net_forward_all(const pf_problem* p, void* stream);
+int pf_net_backward_all(const pf_problem* p, void* stream);
 /* f_int = K(theta) u by node-wise gather of fe = (s*pattern) @ u_elem:
  * nn_assembly.py:64-100 + 226-227 (f_int only; K is never formed).  f_int_out dev [n_dofs]. */
 int pf_internal_force(const pf_problem* p, const float* u, float* f_int_out, void* stream);

@@ -112,6 +112,8 @@ SYMBOLS = {
     "pf_fusion_info": (C.c_int, [_PP]),
     "pf_pack_theta": (C.c_int, [_PP, C.c_void_p]),
     "pf_net_forward": (C.c_int, [_PP, C.c_int, C.c_void_p]),
+    "pf_net_forward_all": (C.c_int, [_PP, C.c_void_p]),
+    "pf_net_backward_all": (C.c_int, [_PP, C.c_void_p]),
     "pf_internal_force": (C.c_int, [_PP, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pf_node_residual": (C.c_int, [_PP, C.c_void_p, C.c_void_p]),
     "pf_elem_adjoint": (C.c_int, [_PP, C.c_void_p]),

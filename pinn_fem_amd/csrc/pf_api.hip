@@ -335,6 +335,31 @@ int pf_net_forward(const pf_problem* p, int which, void* stream) {
   return PF_OK;
 }
 
+int pf_net_forward_all(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  PF_TRY(net_forward_all(p, (hipStream_t)stream), "pf_net_forward_all");
+  return PF_OK;
+}
+
+int pf_net_backward_all(const pf_problem* p, void* stream) {
+  int rc = check_problem(p);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (!(p->net[0].enabled || p->net[1].enabled)) return PF_OK;
+  if (can_fuse_backward(p)) {
+    PF_TRY(net_backward2(p, s), "net_backward2");
+    return PF_OK;
+  }
+  const bool fuse_gea = fuse_gea_for(p);
+  const int first = p->net[0].enabled ? 0 : 1;
+  if (!fuse_gea) PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
+  for (int k = 0; k < 2; ++k)
+    if (p->net[k].enabled)
+      PF_TRY(fuse_gea && k == first ? net_backward_gea(p, k, s) : net_backward(p, k, s), "net_backward");
+  return PF_OK;
+}
+
 int pf_internal_force(const pf_problem* p, const float* u, float* f_int_out, void* stream) {
   int rc = check_problem(p);
   if (rc) return rc;

@@ -772,11 +772,15 @@ int pf_launch_node_gradu(const pf_problem* p, int fuse_adam, hipStream_t s, int 
   const int nb = pf_node_blocks(p->mesh.n_nodes);
   const dim3 g(nb), b(PF_NODE_THREADS);
   const int out_alt = u_out != nullptr && u_out == p->u_alt ? 1 : 0;
+  // PF_GRADU_LDS (experiment knob): dynamic LDS bytes the side-branch launch of the iteration graph (u_out != null) asks
+  // for without using them — caps how many of its blocks a CU holds, so that a forward block always finds room beside them
+  static const int lds_knob = getenv("PF_GRADU_LDS") ? atoi(getenv("PF_GRADU_LDS")) : 0;
+  const size_t lds = u_out ? (size_t)lds_knob : 0;
   if (p->mesh.dim == 2) {
-    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<2, true>), g, b, 0, s, *p, skip_shared, u_out, out_alt);
+    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<2, true>), g, b, lds, s, *p, skip_shared, u_out, out_alt);
     else hipLaunchKernelGGL((k_node_gradu<2, false>), g, b, 0, s, *p, skip_shared, (float*)nullptr, 0);
   } else {
-    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<1, true>), g, b, 0, s, *p, skip_shared, u_out, out_alt);
+    if (fuse_adam) hipLaunchKernelGGL((k_node_gradu<1, true>), g, b, lds, s, *p, skip_shared, u_out, out_alt);
     else hipLaunchKernelGGL((k_node_gradu<1, false>), g, b, 0, s, *p, skip_shared, (float*)nullptr, 0);
   }
   return PF_CHECK_LAUNCH();

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
 // (all blocks compute the same bits); block 0 stores theta, the moments, the images and the theta-norm monitor — see
 // fwd2_theta_prologue.
 template <int NRE, int NRA, int L, int IN>
-__global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg, int s2_half) {
+__global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg, int s2_half, int queue) {
   using EE = Eng<NRE>;
   using EA = Eng<NRA>;
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
@@ -913,12 +913,21 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
     copy_image(smem + IMGP, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[1]), IMG);
   }
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  const int grp = (dbg & 32) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   const int n = P.mesh.n_elems;
   const int ntasks = (n + 63) >> 6;
+  // Two ways to hand the 64-element tasks to the waves.  queue (default): the block owns a contiguous run of tasks and
+  // its waves draw them from a counter in LDS, so no wave ever waits for another one — the age-ordered arbitration of a
+  // SIMD lets its oldest wave run ahead, and with a queue that wave simply takes more tasks (the waves drift out of
+  // phase by themselves).  Lockstep (queue == 0, round 2): block-uniform rounds of one task per wave with ONE s_barrier
+  // per task, passed at a different place of the task body by each of the four wave groups.
+  const int grp = (queue || (dbg & 32)) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   const int per_round = gridDim.x * waves;
   const int rounds = (ntasks + per_round - 1) / per_round;
-  int task = blockIdx.x * waves + wv;
+  const int per_block = (ntasks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t0 = (int)blockIdx.x * per_block, t1 = min(t0 + per_block, ntasks);
+  __shared__ int s_next;
+  if (threadIdx.x == 0) s_next = waves;           // tasks t0 .. t0+waves-1 go to the waves in order, the rest through the queue
+  int task = queue ? t0 + wv : (int)blockIdx.x * waves + wv;
   float xn[3];
   ElemGeo gn = ElemGeo{0.f, 0.f, 0.f, 1.f};
   if (n > 0) {
@@ -937,14 +946,26 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   if (s_done || n <= 0) return;
   const float bo_e = reinterpret_cast<const float*>(img_e + pf_n32_off_bo())[0];
   const float bo_a = reinterpret_cast<const float*>(img_a + pf_n32_off_bo())[0];
-  for (int r = 0; r < rounds; ++r, task += per_round) {
+  for (int r = 0; queue ? task < t1 : r < rounds; ++r) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
+    // the task after this one: drawn now (queue) so that its inputs travel while this one computes
+    int nxt;
+    bool more;
+    if (queue) {
+      int k = 0;
+      if (lane == 0) k = atomicAdd(&s_next, 1);
+      nxt = t0 + __builtin_amdgcn_readfirstlane(k);
+      more = nxt < t1;
+    } else {
+      nxt = task + per_round;
+      more = r + 1 < rounds;
+    }
     const int e = task * 64 + lane;
     float x0[3], x1[3];
     sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
     const ElemGeo g = gn;
-    if (r + 1 < rounds) {
-      const int en = min(e + per_round * 64, n - 1);
+    if (more) {
+      const int en = min(nxt * 64 + lane, n - 1);
       load_x<IN>(xn, P, en);
       gn = load_geo(P.mesh.egeo, en);
     }
@@ -969,11 +990,10 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
       if (P.elem_k) store_k<IN - 1>(P.elem_k, e, g, (ve * va) / g.l0);    // (young * area) / l0, nn_assembly.py:74, :37
     }
     if (grp == 3) __builtin_amdgcn_s_barrier();
+    task = nxt;
   }
 }
 
-// GEA: this launch also computes dL/d(E*A) per element (the element adjoint) and stores it for the other net's
-// backward.  Partial gradient row of the block: the padded image of pf_common.h (what theta_stage1 sums).
 // Stores of a block's partial gradient row; wt: agent-scope write-through (global_store ... sc1).  With PF_FUSE_S1=1 the
 // fused backward launch hands the rows to the LAST block of each row group inside the launch (rows_reduce_last below), and a hand-off without a
 // release fence needs every handed-off byte stored this way (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms).
@@ -1336,7 +1356,9 @@ int launch_fwd2_t(const pf_problem* p, hipStream_t s, int s2_half) {
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;
   const size_t lds = 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255) + (s2_half < 0 ? 0 : (size_t)p->n_theta_active * sizeof(float));
   if (lds > 64000) { pf_set_error("too many trainable parameters for the fused theta update"); return PF_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half);
+  // PF_FWD_QUEUE=0: experiment knob (round 2's lockstep rounds instead of the per-block task queue)
+  static const int queue = getenv("PF_FWD_QUEUE") ? atoi(getenv("PF_FWD_QUEUE")) : 1;
+  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half, queue);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>

@@ -351,6 +351,24 @@ class HipEngine:
         return np.array(list(out), dtype=np.float64)
 
     @_on_engine_stream
+    def time_step_launch(self, what: str, reps: int = 20) -> float:
+        """Average device time (ms) of `reps` back-to-back launches of one step of the current iteration state — "backward":
+        the backward pass of every enabled net incl. the element adjoint, "forward": the forward pass of every enabled net —
+        between two HIP events on the engine's stream (no launch gaps inside: the launches queue up behind each other).
+        Idempotent steps: they read the state and rewrite workspaces only."""
+        fn = {"backward": self.lib.pf_net_backward_all, "forward": self.lib.pf_net_forward_all}[what]
+        s = self._stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            _capi.check(fn(self._ref(), s), what)
+        e0.record(self.stream)
+        for _ in range(int(reps)):
+            _capi.check(fn(self._ref(), s), what)
+        e1.record(self.stream)
+        e1.synchronize()
+        return e0.elapsed_time(e1) / float(reps)
+
+    @_on_engine_stream
     def state(self) -> PfState:
         raw = self.state_t.cpu().numpy().tobytes()
         return PfState.from_buffer_copy(raw)
