@@ -44,10 +44,15 @@ __host__ __device__ constexpr int pf_n32_bytes(int n_hidden) { return pf_n32_off
 // prec 0: split f16 (hi, lo); prec 1: plain bf16 in the hi slots (round to nearest), lo slots zero.
 // with_bound: also compute the header's backward-scaling bound (only the backward kernels read it: a forward launch that
 // builds the image in its own LDS skips it).
-__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, int prec, bool with_bound = true) {
+// t_first, t_count: the (multiple of 64) thread range of the block that does the work (default: the whole block), so that
+// two nets can be packed side by side by the two halves of a block; threads outside the range return at once.
+__device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned char* img, int prec, bool with_bound = true,
+                                   int t_first = 0, int t_count = 0) {
   const int W = net.width, L = net.n_hidden, IN = net.in_dim;
   const int o_b1 = W * IN, o_h = W * IN + W, per = W * W + W, o_wo = o_h + (L - 1) * per, o_bo = o_wo + W;
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int nt = t_count > 0 ? t_count : (int)blockDim.x;
+  const int tid = (int)threadIdx.x - t_first;
+  if (tid < 0 || tid >= nt) return;
   // layer 1 rows and the output row (float)
   float4* w1 = reinterpret_cast<float4*>(img + pf_n32_off_w1());
   for (int i = tid; i < 32; i += nt) {

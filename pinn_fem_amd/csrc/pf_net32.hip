@@ -760,8 +760,8 @@ struct Eng {
 // images of the enabled nets straight into LDS (img_lds[k]; null: that net's image is not needed by this launch).  Block 0
 // also stores the new state into the other half, the images (with the backward's scaling bound) and the theta-norm
 // monitor to global memory and flips state->theta_half: nothing any block of this launch reads.  Two block barriers.
-__device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half_in, unsigned char* const (&img_lds)[2],
-                                                   float* new_theta, int img_bytes, int* s_done) {
+__device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half_in, unsigned char* img_lds0,
+                                                   unsigned char* img_lds1, float* new_theta, int img_bytes, int* s_done) {
   const bool lead = blockIdx.x == 0;
   // The stop flag is stable while a forward launch runs (the bookkeeping that raises it is ordered behind it), so the lead
   // block may read it for itself, and every block's update loads leave together with the block's one flag read instead
@@ -771,12 +771,18 @@ __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half
   pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1);
   __syncthreads();
   if (*s_done) return;
-  for (int k = 0; k < 2; ++k) {
-    if (!P.net[k].enabled) continue;
+  // (two nets: the two halves of the block pack them side by side)
+  const bool two = P.net[0].enabled && P.net[1].enabled && blockDim.x >= 256;
+  const int half = two ? ((int)blockDim.x / 2) & ~63 : 0;
+  auto pack_net = [&](int k, unsigned char* lds_img) {
+    if (!P.net[k].enabled) return;
     unsigned char* gimg = reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]);
-    if (img_lds[k]) pf_n32_pack(P.net[k], new_theta + P.net[k].theta_off, img_lds[k], P.mlp_dtype, lead);
-    else if (lead) pf_n32_pack(P.net[k], new_theta + P.net[k].theta_off, gimg, P.mlp_dtype, true);
-  }
+    const int t_first = two ? k * half : 0, t_count = two ? (k == 0 ? half : (int)blockDim.x - half) : 0;
+    if (lds_img) pf_n32_pack(P.net[k], new_theta + P.net[k].theta_off, lds_img, P.mlp_dtype, lead, t_first, t_count);
+    else if (lead) pf_n32_pack(P.net[k], new_theta + P.net[k].theta_off, gimg, P.mlp_dtype, true, t_first, t_count);
+  };
+  pack_net(0, img_lds0);
+  pack_net(1, img_lds1);
   __shared__ float tnorm[PF_MAX_TENSORS];
   if (lead) {
     // (the theta norm from the LDS copy, one wave per tensor in turn; inactive parameters come from p->theta)
@@ -784,9 +790,8 @@ __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half
   }
   __syncthreads();
   if (lead) {
-    for (int k = 0; k < 2; ++k)
-      if (P.net[k].enabled && img_lds[k])
-        copy_image(reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]), img_lds[k], img_bytes);
+    if (P.net[0].enabled && img_lds0) copy_image(reinterpret_cast<unsigned char*>(P.net_op + P.op_off[0]), img_lds0, img_bytes);
+    if (P.net[1].enabled && img_lds1) copy_image(reinterpret_cast<unsigned char*>(P.net_op + P.op_off[1]), img_lds1, img_bytes);
     if (threadIdx.x == 0) {
       P.state->theta_norm = (float)tensor_norm_total(P, tnorm);
       P.state->theta_half = half_in ^ 1;
@@ -840,9 +845,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
   // disagreed would part ways before the lockstep barriers below)
   __shared__ int s_done;
   if (s2_half >= 0) {
-    unsigned char* const imgs[2] = {which == 0 ? smem : nullptr, which == 1 ? smem : nullptr};
-    fwd_theta_prologue(P, s2_half, imgs, reinterpret_cast<float*>(smem + ((pf_n32_bytes(L) + 255) & ~255)), pf_n32_bytes(L),
-                       &s_done);
+    fwd_theta_prologue(P, s2_half, which == 0 ? smem : nullptr, which == 1 ? smem : nullptr,
+                       reinterpret_cast<float*>(smem + ((pf_n32_bytes(L) + 255) & ~255)), pf_n32_bytes(L), &s_done);
   } else {
     if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
@@ -937,8 +941,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   }
   __shared__ int s_done;
   if (s2_half >= 0) {
-    unsigned char* const imgs[2] = {smem, smem + IMGP};
-    fwd_theta_prologue(P, s2_half, imgs, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done);
+    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done);
   } else {
     if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
