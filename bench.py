@@ -291,7 +291,7 @@ def main():
 
     n_local = args.elems if args.total_elems <= 0 else args.total_elems // world
     lr_t = 5e-4 if args.workload == "ex4" else 1e-3
-    cfg = SolverConfig(max_iterations=max(args.warmup, 50) + (2 + max(args.repeat, 0)) * args.steps + 64, tolerance=0.0,
+    cfg = SolverConfig(max_iterations=max(args.warmup, 50) + (3 + max(args.repeat, 0)) * args.steps + 64, tolerance=0.0,
                        learning_rate_u=0.01, learning_rate_theta=lr_t, alpha_physics=1.0, alpha_data=100.0)
     if world == 1:
         from pinn_fem_amd.engine import HipEngine
@@ -334,8 +334,14 @@ def main():
         eng.begin(None, 0.1, cfg)
         eng.prepare()
         iters_before = 0
-    # (2) W untimed warm-up steps, (3) EXACTLY K timed steps between barrier + synchronize
+    # (2) W untimed warm-up steps — the last K of them issued exactly like the timed region (synchronise, K steps,
+    # synchronise): the first region issued that way after a burst of back-to-back replays read 3-6 us per step above all
+    # later ones whatever the length of the burst (60, 200, 500 iterations) — (3) EXACTLY K timed steps between barrier +
+    # synchronize
     run_warm(n_warm)
+    torch.cuda.synchronize(dev)
+    run_timed(args.steps)
+    n_warm += args.steps
     graphs_before = graph_count()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -467,7 +473,8 @@ def main():
                                    f"{n_local} elements per GPU, collinear 2-D truss h=1, "
                                    f"alpha_data=100 with measurements at every node, load factor 0.1",
                        "elements_total": total_elems, "parallelism": f"elements sharded x{world}"},
-            "repeat": ({"regions": len(rep_ms), "steps_each": args.steps, "ms_per_step_median": float(np.median(rep_ms)),
+            "repeat": ({"regions": len(rep_ms), "steps_each": args.steps, "ms_per_step_each": [float(x) for x in rep_ms],
+                        "ms_per_step_median": float(np.median(rep_ms)),
                         "ms_per_step_min": float(np.min(rep_ms)), "ms_per_step_max": float(np.max(rep_ms)),
                         "value_at_median": total_elems * 1e3 / float(np.median(rep_ms))} if rep_ms else None),
             "ms_per_step_eager_with_events": dt_events / args.steps * 1e3,
