@@ -24,7 +24,8 @@ PF_COMM_ID_BYTES = 128
 PF_MAX_NODE_BLOCKS = 4096
 PF_NODE_SLOTS = PF_MAX_NODE_BLOCKS + 8
 PF_KERNEL_SLOTS = 9
-PF_FUSED_FORWARD, PF_FUSED_BACKWARD, PF_FUSED_THETA_UPDATE, PF_FUSED_U_PINGPONG = 1, 2, 4, 8
+PF_FUSED_FORWARD, PF_FUSED_BACKWARD, PF_FUSED_THETA_UPDATE, PF_FUSED_U_PINGPONG, PF_FUSED_U_UPDATE = 1, 2, 4, 8, 16
+PF_FUSED_ROW_REDUCTION = 32
 KERNEL_SLOT_NAMES = ("net_forward_young", "net_forward_area", "node_residual", "elem_adjoint",
                      "net_backward_young", "net_backward_area", "node_gradu_adam", "theta_reduce_adam",
                      "finalize")

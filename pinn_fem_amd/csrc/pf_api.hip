@@ -153,23 +153,25 @@ static bool can_fuse_forward(const pf_problem* p) {
 }
 #define PF_NR0_SWITCH(PREFIX)                                     \
   switch (pf_net32_bucket(p->net[0].width)) {                     \
-    case 2: return PREFIX##2(p, s, s2_half);                      \
-    case 4: return PREFIX##4(p, s, s2_half);                      \
-    case 6: return PREFIX##6(p, s, s2_half);                      \
-    case 8: return PREFIX##8(p, s, s2_half);                      \
-    case 10: return PREFIX##10(p, s, s2_half);                    \
-    case 12: return PREFIX##12(p, s, s2_half);                    \
-    case 15: return PREFIX##15(p, s, s2_half);                    \
+    case 2: return PREFIX##2(p, s, o);  \
+    case 4: return PREFIX##4(p, s, o);  \
+    case 6: return PREFIX##6(p, s, o);  \
+    case 8: return PREFIX##8(p, s, o);  \
+    case 10: return PREFIX##10(p, s, o);  \
+    case 12: return PREFIX##12(p, s, o);  \
+    case 15: return PREFIX##15(p, s, o);  \
   }                                                               \
   return fail(PF_ERR_UNSUPPORTED, "MFMA32 engine: net width outside 1..30");
-static int net_forward2(const pf_problem* p, hipStream_t s, int s2_half = -1) {
+static int net_forward2(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o = pf_fwd2_opts()) {
   if (p->mlp_dtype == PF_MLP_BF16) { PF_NR0_SWITCH(pf_launch_net32b_forward2_) }
   PF_NR0_SWITCH(pf_launch_net32_forward2_)
 }
 // the forward pass of every enabled net: the properties and, with the MFMA32 engine, the stiffness records.
 // s2_half >= 0: the FIRST launch also runs the parameter update of the previous iteration (can_fuse_theta_update)
-static int net_forward_all(const pf_problem* p, hipStream_t s, int s2_half = -1) {
-  if (can_fuse_forward(p)) return net_forward2(p, s, s2_half);
+// o.gu_nb / o.s1_rows (only with can_fuse_gradu / can_fuse_stage1; fused launch only): see pf_fwd2_opts
+static int net_forward_all(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o = pf_fwd2_opts()) {
+  if (can_fuse_forward(p)) return net_forward2(p, s, o);
+  int s2_half = o.s2_half;
   for (int k = 0; k < 2; ++k)
     if (p->net[k].enabled) {
       const int rc = net_forward(p, k, s, k == 1 || !p->net[1].enabled, s2_half);
@@ -184,6 +186,23 @@ static bool can_fuse_theta_update(const pf_problem* p) {
   static const int knob = getenv("PF_FUSE_S2") ? atoi(getenv("PF_FUSE_S2")) : 1;
   return knob != 0 && p->wg_mode == PF_WG_MFMA32 && p->theta_alt != nullptr && p->n_theta_active > 0 &&
          (p->net[0].enabled || p->net[1].enabled);
+}
+
+// Can the fused forward launch that carries the parameter update also do the first level of the gradient-row reduction
+// (k_theta_stage1's work: its first PF_RG blocks sum one row group each and hand the second-level rows to every block of
+// the launch through write-through stores and a counter)?  One launch and one boundary less per iteration.
+// PF_FUSE_S1F=0: experiment knob (stand-alone theta stage 1 launch).
+static bool can_fuse_stage1(const pf_problem* p) {
+  static const int knob = getenv("PF_FUSE_S1F") ? atoi(getenv("PF_FUSE_S1F")) : 1;
+  return knob != 0 && can_fuse_forward(p) && can_fuse_theta_update(p);
+}
+
+// Can the iteration graph fold the displacement update (dL/du + Adam(u) + clamp) of iteration t into the fused forward
+// launch of t+1 (pf_net32.hip: k_net32_forward2, gu_nb; pf_node.h)?  The graph is then a plain chain: no side branch, no
+// fork, no join, no second displacement vector.  PF_FUSE_GU=0: experiment knob (gradu on its own branch, as in round 2).
+static bool can_fuse_gradu(const pf_problem* p) {
+  static const int knob = getenv("PF_FUSE_GU") ? atoi(getenv("PF_FUSE_GU")) : 1;
+  return knob != 0 && can_fuse_forward(p) && pf_n32_fwd2_can_update_u(p, pf_node_blocks(p->mesh.n_nodes));
 }
 
 static int net_backward(const pf_problem* p, int which, hipStream_t s) {
@@ -316,7 +335,9 @@ int pf_fusion_info(const pf_problem* p) {
   if (can_fuse_forward(p)) m |= PF_FUSED_FORWARD;
   if (can_fuse_backward(p)) m |= PF_FUSED_BACKWARD;
   if (can_fuse_theta_update(p)) m |= PF_FUSED_THETA_UPDATE;
-  if (p->u_alt != nullptr && p->mesh.n_elems >= PF_GRAPH_DAG_MIN_ELEMS) m |= PF_FUSED_U_PINGPONG;
+  if (p->prop_double != 0 && p->elem_k != nullptr && can_fuse_gradu(p)) m |= PF_FUSED_U_UPDATE;
+  if (can_fuse_stage1(p)) m |= PF_FUSED_ROW_REDUCTION;
+  else if (p->u_alt != nullptr && p->mesh.n_elems >= PF_GRAPH_DAG_MIN_ELEMS) m |= PF_FUSED_U_PINGPONG;
   return m;
 }
 
@@ -520,7 +541,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   hipStream_t s = c.s;
   // PF_GRAPH_SERIAL=1: experiment knob, the plain chain of launches inside the graph (no branches)
   static const int serial_knob = getenv("PF_GRAPH_SERIAL") ? atoi(getenv("PF_GRAPH_SERIAL")) : -1;
-  const bool serial = serial_knob >= 0 ? serial_knob != 0 : p->mesh.n_elems < PF_GRAPH_DAG_MIN_ELEMS;
+  bool serial = serial_knob >= 0 ? serial_knob != 0 : p->mesh.n_elems < PF_GRAPH_DAG_MIN_ELEMS;
   if (!any_net) {
     for (int i = 0; i < iters; ++i) {
       int rc = enqueue_iteration(p, 1, 0, s, nullptr);
@@ -531,6 +552,14 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   // serial: the same kernels as ONE chain on `s` (no side branch, no events): forward, residual [+ finalize of the
   // previous iteration in its block 0], backwards, theta stage 1, gradu — neither the bookkeeping nor the parameter update
   // costs a launch of its own there either.
+  static const bool pp_knob = !(getenv("PF_GRAPH_PINGPONG") && atoi(getenv("PF_GRAPH_PINGPONG")) == 0);
+  const bool pingpong = p->prop_double != 0 && pp_knob;
+  // The displacement update of iteration i-1 (dL/du + Adam(u) + clamp) runs INSIDE iteration i's forward launch, as node
+  // tasks between its element tasks (can_fuse_gradu; it reads the stiffness records of i-1 = the other half, which is
+  // why it needs the two halves): the graph is then ONE chain.  Only the replay's last iteration keeps the stand-alone
+  // kernel, in place.
+  const bool fuse_gu = pingpong && p->elem_k != nullptr && can_fuse_gradu(p);
+  if (fuse_gu) serial = true;
   hipStream_t sa = serial ? s : c.a;
   auto ev_wait = [&](hipStream_t st, hipEvent_t e) { return serial || hipStreamWaitEvent(st, e, 0) == hipSuccess; };
   auto ev_rec = [&](hipEvent_t e, hipStream_t st) { return serial || hipEventRecord(e, st) == hipSuccess; };
@@ -542,20 +571,22 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   // the bookkeeping kernel has NO node of its own: finalize(i-1) runs as block 0 of node_residual(i)
   // (pf_mesh.hip: k_node_residual, fin_prev) from the other half of the residual's partial sums
   // (pf_problem.part_half), finalize of the graph's last iteration as a stand-alone launch at its end.
-  static const bool pp_knob = !(getenv("PF_GRAPH_PINGPONG") && atoi(getenv("PF_GRAPH_PINGPONG")) == 0);
-  const bool pingpong = p->prop_double != 0 && pp_knob;
   const int tn_ready = p->wg_mode == PF_WG_MFMA32 ? 1 : 0;   // k_theta_stage2 leaves the theta-norm monitor in the state
   // The parameter update of iteration i-1 (theta stage 2: second-level rows -> Adam -> operand images) runs in the
   // PROLOGUE of iteration i's forward launch, by every block for itself (pf_net32.hip: fwd_theta_prologue); the state
   // ping-pongs between its two halves so that block 0's stores never meet another block's loads.  Only the replay's
   // last iteration keeps the stand-alone update, which also brings the state back to half 0.
   const bool fuse_s2 = can_fuse_theta_update(p);
+  // ... and the first reduction level of the gradient rows with it (can_fuse_stage1): the chain of an iteration is then
+  // forward (+ both updates of the previous iteration) -> residual (+ bookkeeping) -> backward
+  const bool fuse_s1f = fuse_s2 && can_fuse_stage1(p) && !fuse_s1_knob();
   // Displacement vectors ping-pong too (pf_problem.u_alt; DAG form, even replay length): the update of iteration i reads
   // U[i & 1] like the residual and the element adjoint of i and WRITES U[(i + 1) & 1], so it forks right behind the
   // residual and runs beside the whole backward launch.  PF_GRAPH_UPP=0: experiment knob (in place, fork behind the
   // adjoint's last read of u).
   static const bool upp_knob = !(getenv("PF_GRAPH_UPP") && atoi(getenv("PF_GRAPH_UPP")) == 0);
   const bool upp = !serial && upp_knob && p->u_alt != nullptr && (iters % 2) == 0;
+  const float* c_elem_k = p->elem_k;
   for (int i = 0; i < iters; ++i) {
     hipEvent_t* e = c.ev + PF_CAP_EV * i;
     hipEvent_t* ep = c.ev + PF_CAP_EV * (i - 1);
@@ -579,7 +610,18 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     if (i > 0 && !pingpong && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
     // (both nets in one launch where the engine has it; else one after the other: side by side on two branches they
     // measured slower, the same issue pipe, and the second one writes the stiffness records from both)
-    PF_TRY(net_forward_all(p, s, fuse_s2 && i > 0 ? ((i - 1) & 1) : -1), "net_forward");
+    const float* k_prev = nullptr;        // the records iteration i-1 wrote (the other half)
+    if (fuse_gu && i > 0) k_prev = ((i - 1) & 1) ? c_elem_k + (size_t)q.mesh.n_elems * (q.mesh.dim == 2 ? 3 : 1) : c_elem_k;
+    pf_fwd2_opts fo;
+    if (fuse_s2 && i > 0) {
+      fo.s2_half = (i - 1) & 1;
+      if (fuse_s1f) fo.s1_rows = pf_net_blocks(p);      // (no stand-alone stage 1 behind the backward of i-1)
+    }
+    if (k_prev) {
+      fo.gu_nb = pf_node_blocks(q.mesh.n_nodes);
+      fo.gu_k = k_prev;
+    }
+    PF_TRY(net_forward_all(p, s, fo), "net_forward");
     // residual(i) reads u(i) [gradu(i-1)]; its block 0 is finalize(i-1): behind the theta update of i-1 (this chain:
     // the forward launch above, or the stand-alone kernel) and gradu(i-1)
     if (i > 0 && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
@@ -600,15 +642,17 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
         if (!upp && fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
       }
     }
-    if (!(can_fuse_backward(p) && fuse_s1_knob())) PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
+    if (!(can_fuse_backward(p) && fuse_s1_knob()) && !(fuse_s1f && i < iters - 1))
+      PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
     if (!fuse_s2 || i == iters - 1) PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
     // branch A (created after the main chain's nodes of this iteration): gradu behind the last reader of u
+    if (fuse_gu && i < iters - 1) continue;           // (the next forward launch carries it)
     if (!ev_wait(sa, e[0])) return fail(PF_ERR_HIP, "graph edge failed");
     PF_TRY(pf_launch_node_gradu(p, 1, sa, 0, u_next), "node_gradu");
     if (!ev_rec(e[1], sa)) return fail(PF_ERR_HIP, "graph edge failed");
   }
   // finalize of the last iteration: behind stage 2 (this chain) and the last gradu
-  if (!ev_wait(s, c.ev[PF_CAP_EV * (iters - 1) + 1])) return fail(PF_ERR_HIP, "graph join failed");
+  if (!serial && !ev_wait(s, c.ev[PF_CAP_EV * (iters - 1) + 1])) return fail(PF_ERR_HIP, "graph join failed");
   if (upp) PF_TRY(pf_launch_u_home(p, s), "u_home");      // (only a stop in mid-replay leaves anything to copy)
   {
     pf_problem q = *p;
@@ -627,8 +671,13 @@ static int capture_graph(hipStream_t s, int nev, hipStreamCaptureMode mode, void
   hipStream_t side[2] = {nullptr, nullptr};
   hipEvent_t* ev = new hipEvent_t[nev];
   int made = 0;
-  bool ok = hipStreamCreateWithFlags(&side[0], hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&side[1], hipStreamNonBlocking) == hipSuccess;
+  // PF_GRAPH_SIDE_PRIO (experiment knob): priority of the capture's side streams (-1 high, 0 default, 1 low)
+  static const int prio_knob = getenv("PF_GRAPH_SIDE_PRIO") ? atoi(getenv("PF_GRAPH_SIDE_PRIO")) : 0;
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  const int prio = prio_knob < 0 ? hi : (prio_knob > 0 ? lo : 0);
+  bool ok = hipStreamCreateWithPriority(&side[0], hipStreamNonBlocking, prio) == hipSuccess &&
+            hipStreamCreateWithPriority(&side[1], hipStreamNonBlocking, prio) == hipSuccess;
   for (; ok && made < nev; ++made)
     if (hipEventCreateWithFlags(&ev[made], hipEventDisableTiming) != hipSuccess) break;
   ok = ok && made == nev;

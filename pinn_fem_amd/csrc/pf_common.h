@@ -124,8 +124,10 @@ __device__ __forceinline__ float* pf_theta_half_ptr(const pf_problem& P, int hal
 // when non-null.  The state is read from half `half_in` and stored to half `half_out` (0, 0: in place).
 // skip_stores: compute only (the block-uniform stop flag as loaded by the caller — the loads below are then issued WITH
 // that load instead of behind a branch on it; or a block of the forward launch that only needs its own copy).
+// wt_loads: the second-level rows were stored write-through by OTHER blocks of this very launch (pf_net32.hip:
+// stage1_group inside the forward launch): read them with agent-scope (sc1) loads, behind the caller's poll + barrier.
 __device__ __forceinline__ void pf_theta_update(const pf_problem& P, int fuse_adam, float* new_theta, int skip_stores = 0,
-                                                int half_in = 0, int half_out = 0) {
+                                                int half_in = 0, int half_out = 0, bool wt_loads = false) {
   PF_NO_CONTRACT
   const float* __restrict__ p2 = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total;
   const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
@@ -144,7 +146,10 @@ __device__ __forceinline__ void pf_theta_update(const pf_problem& P, int fuse_ad
     if (fuse_adam) { m = m_i[q]; v = v_i[q]; }
     float g = 0.f;
 #pragma unroll
-    for (int r = 0; r < PF_RG; ++r) g += p2[(size_t)r * P.pad_total + pi];
+    for (int r = 0; r < PF_RG; ++r) {
+      const float* src = p2 + (size_t)r * P.pad_total + pi;
+      g += wt_loads ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+    }
     if (fuse_adam) {
       m = m + b1w * (g - m);
       v = v * b2;
@@ -222,14 +227,16 @@ __device__ __forceinline__ ElemK elem_k_unit(const ElemGeo& g) {
   return ElemK{1.f, 0.f, 0.f};
 }
 template <int DIM>
-__device__ __forceinline__ ElemK load_k(const pf_problem& P, int e) {
-  if (P.elem_k) {
-    if (DIM == 2) {
-      const float* __restrict__ r = P.elem_k + 3 * (size_t)e;
-      return ElemK{r[0], r[1], r[2]};
-    }
-    return ElemK{P.elem_k[e], 0.f, 0.f};
+__device__ __forceinline__ ElemK load_k_record(const float* __restrict__ elem_k, int e) {
+  if (DIM == 2) {
+    const float* __restrict__ r = elem_k + 3 * (size_t)e;
+    return ElemK{r[0], r[1], r[2]};
   }
+  return ElemK{elem_k[e], 0.f, 0.f};
+}
+template <int DIM>
+__device__ __forceinline__ ElemK load_k(const pf_problem& P, int e) {
+  if (P.elem_k) return load_k_record<DIM>(P.elem_k, e);
   const ElemGeo g = load_geo(P.mesh.egeo, e);
   return elem_k_from<DIM>(g, elem_stiffness(P, e, g.l0));
 }
@@ -369,6 +376,17 @@ PF_DECL_NET_LAUNCHERS(24)
 PF_DECL_NET_LAUNCHERS(28)
 PF_DECL_NET_LAUNCHERS(32)
 
+// What a fused forward launch (pf_net32.hip: k_net32_forward2) does besides the two forward passes (the iteration graph):
+//   s2_half >= 0  the parameter update of the previous iteration from that state half (fwd_theta_prologue)
+//   s1_rows > 0   ... and the first level of its gradient-row reduction (what k_theta_stage1 does for s1_rows rows)
+//   gu_nb > 0     the displacement update of the previous iteration (pf_node.h) reading the stiffness records gu_k; gu_nb =
+//                 entries of the u-norm partial sums the bookkeeping reads
+struct pf_fwd2_opts {
+  int s2_half = -1;
+  int s1_rows = 0;
+  int gu_nb = 0;
+  const float* gu_k = nullptr;
+};
 // launchers of pf_net32.hip, one translation unit per register bucket (-DPF_NR=<nr>): nets of width <= 2*nr
 #define PF_DECL_NET32_LAUNCHERS(NRB)                                                       \
   int pf_launch_net32_forward_##NRB(const pf_problem* p, int which, hipStream_t s, int s2_half); \
@@ -377,8 +395,8 @@ PF_DECL_NET_LAUNCHERS(32)
   int pf_launch_net32b_forward_##NRB(const pf_problem* p, int which, hipStream_t s, int s2_half); \
   int pf_launch_net32b_backward_##NRB(const pf_problem* p, int which, hipStream_t s);     \
   int pf_launch_net32b_backward_gea_##NRB(const pf_problem* p, int which, hipStream_t s); \
-  int pf_launch_net32_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);    \
-  int pf_launch_net32b_forward2_##NRB(const pf_problem* p, hipStream_t s, int s2_half);   \
+  int pf_launch_net32_forward2_##NRB(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o);    \
+  int pf_launch_net32b_forward2_##NRB(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o);   \
   int pf_launch_net32_backward2_##NRB(const pf_problem* p, hipStream_t s, int reduce_rows); \
   int pf_launch_net32b_backward2_##NRB(const pf_problem* p, hipStream_t s, int reduce_rows);
 PF_DECL_NET32_LAUNCHERS(2)

@@ -15,6 +15,7 @@
 // atomics and is bitwise reproducible.  K is never formed: K u and K^T g are applied matrix-free.
 #include <stdlib.h>
 #include "pf_common.h"
+#include "pf_node.h"
 #include "pf_net32.h"
 
 // (PF_NO_CONTRACT, the parameter update pf_theta_update and the theta-norm helpers live in pf_common.h: the MFMA32
@@ -160,10 +161,7 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
   if (FUSE_ADAM && u_out && blockIdx.x == 0 && threadIdx.x == 0) P.state->u_half = out_alt;
   __shared__ float red[16];
   const pf_mesh& M = P.mesh;
-  const float step_size = P.state->step_size_u, bc2s = P.state->bc2_sqrt;
-  const float b1w = (float)(1.0 - P.beta1), b2 = (float)P.beta2, b2w = (float)(1.0 - P.beta2);
-  const float eps = (float)P.eps;
-  const float dcoef = P.n_meas_f > 0.f ? P.alpha_data / P.n_meas_f : 0.f;  // mean backward
+  const GraduConsts K = gradu_consts(P);
   float sum_u2 = 0.f;
   for (int node = blockIdx.x * blockDim.x + threadIdx.x; node < M.n_nodes;
        node += gridDim.x * blockDim.x) {
@@ -174,12 +172,9 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
       const int dof = node * DIM + c;
       const unsigned fl = M.dof_flags[dof];
       if (skip_shared && (fl & PF_DOF_SHARED)) continue;
-      float gu = g[c];
       float uo = P.u[dof];
-      if (P.use_data && (fl & PF_DOF_MEASURED)) {
-        const float d = M.meas_val[dof] - uo;
-        gu += -(dcoef * (2.f * d));                   // d(alpha_d*mean d^2)/du
-      }
+      const bool measured = P.use_data && (fl & PF_DOF_MEASURED);
+      const float gu = dof_grad_u(K, measured, g[c], measured ? M.meas_val[dof] : 0.f, uo);   // (pf_node.h)
       if (P.grad_u) P.grad_u[dof] = gu;
       if (FUSE_ADAM) {
         if (fl & PF_DOF_FIXED) {
@@ -189,13 +184,8 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
           else if (uo != 0.f) P.u[dof] = 0.f;
           continue;
         }
-        // torch.optim.Adam single-tensor arithmetic (torch/optim/adam.py)
         float m = P.m_u[dof], v = P.v_u[dof];
-        m = m + b1w * (gu - m);                       // lerp_
-        v = v * b2;                                   // mul_
-        v = v + (b2w * gu) * gu;                      // addcmul_
-        const float denom = sqrtf(v) / bc2s + eps;
-        uo = uo + (-step_size) * (m / denom);         // addcdiv_
+        dof_adam_u(K, gu, uo, m, v);                    // torch.optim.Adam single-tensor arithmetic
         if (!(fl & PF_DOF_GHOST)) sum_u2 += uo * uo;
         P.m_u[dof] = m;
         P.v_u[dof] = v;

@@ -139,3 +139,28 @@ __device__ inline void pf_n32_pack(const pf_net& net, const float* th, unsigned 
     }
   }
 }
+
+// ---- host side of the fused forward launch (pf_net32.hip: k_net32_forward2) ------------------------------------------
+// blocks of the fused forward launch: one 1024-thread block per CU (PF_FWD32_BLOCKS: experiment knob)
+inline int pf_n32_fwd2_blocks(int n_elems) {
+  static const int cap = getenv("PF_FWD32_BLOCKS") ? atoi(getenv("PF_FWD32_BLOCKS")) : 256;
+  int nb = (n_elems + 1023) / 1024;
+  if (nb > cap) nb = cap;
+  if (nb < 1) nb = 1;
+  return nb;
+}
+// nodes per lane of a node task inside the fused forward launch (k_net32_forward2, gu_nb)
+#ifndef PF_GU_M
+#define PF_GU_M 2
+#endif
+// Can the fused forward launch also run the displacement update of the previous iteration (gu_nb = entries of the
+// u-norm partial sums the bookkeeping reads)?  It needs the other-end adjacency, a single-GPU mesh (no ghost elements, no
+// shared dofs), every block's partial inside what the bookkeeping sums, and its node tasks inside the block's LDS table.
+inline bool pf_n32_fwd2_can_update_u(const pf_problem* p, int gu_nb) {
+  if (!p->adj_other || !p->m_u || !p->v_u || p->mesh.n_elems <= 0) return false;
+  if (p->n_shared != 0 || p->own_lo != 0 || p->own_hi != 0) return false;
+  const int nb = pf_n32_fwd2_blocks(p->mesh.n_elems);
+  if (nb > gu_nb) return false;
+  const int ntasks = (p->mesh.n_nodes + 64 * PF_GU_M - 1) / (64 * PF_GU_M);
+  return (ntasks + nb - 1) / nb <= 1024 - 16;
+}

@@ -26,6 +26,7 @@
 #include <type_traits>
 #include <stdlib.h>
 #include "pf_net32.h"
+#include "pf_node.h"
 
 #ifndef PF_NR
 #error "compile with -DPF_NR=<registers per lane>"
@@ -754,6 +755,39 @@ struct Eng {
 
 };
 
+// Stores of a block's partial gradient row; wt: agent-scope write-through (global_store ... sc1).  With PF_FUSE_S1=1 the
+// fused backward launch hands the rows to the LAST block of each row group inside the launch (rows_reduce_last below), and a hand-off without a
+// release fence needs every handed-off byte stored this way (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms).
+__device__ __forceinline__ void row_store(float* p, float v, bool wt) {
+  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;                                       // (the usual case: the rows are read by the NEXT launch)
+}
+__device__ __forceinline__ float row_load(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The arithmetic of k_theta_stage1 for row group g, by one whole block: four interleaved row sums per column, combined
+// (0 + 1) + (2 + 3).  wt_loads: the rows were stored write-through inside this launch; wt_store: the group's row is handed to
+// other blocks of this launch (agent-scope store).
+__device__ __forceinline__ void stage1_group(const pf_problem& P, int nb_rows, int g, bool wt_loads, bool wt_store) {
+  const int rpg = (nb_rows + PF_RG - 1) / PF_RG;
+  const int r0 = g * rpg, r1 = min(r0 + rpg, nb_rows);
+  float* __restrict__ out = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total + (size_t)g * P.pad_total;
+  for (int col = threadIdx.x; col < P.pad_total; col += blockDim.x) {
+    const float* rows = P.partials + PF_PART_WG + col;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r1; r += 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (r + k < r1) {
+          const float* src = rows + (size_t)(r + k) * P.pad_total;
+          a[k] += wt_loads ? row_load(src) : *src;
+        }
+    }
+    row_store(out + col, (a[0] + a[1]) + (a[2] + a[3]), wt_store);
+  }
+}
+
 // ---- the parameter update of the PREVIOUS iteration, run by a forward launch for itself (pf_problem.theta_alt) --------
 // Every block: second-level partial rows -> gradient -> Adam step from state half `half_in` (pf_theta_update: the
 // arithmetic of the stand-alone update kernel, bit for bit) -> its own LDS copy of the new parameters -> the operand
@@ -761,14 +795,15 @@ struct Eng {
 // also stores the new state into the other half, the images (with the backward's scaling bound) and the theta-norm
 // monitor to global memory and flips state->theta_half: nothing any block of this launch reads.  Two block barriers.
 __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half_in, unsigned char* img_lds0,
-                                                   unsigned char* img_lds1, float* new_theta, int img_bytes, int* s_done) {
+                                                   unsigned char* img_lds1, float* new_theta, int img_bytes, int* s_done,
+                                                   bool wt_rows = false) {
   const bool lead = blockIdx.x == 0;
   // The stop flag is stable while a forward launch runs (the bookkeeping that raises it is ordered behind it), so the lead
   // block may read it for itself, and every block's update loads leave together with the block's one flag read instead
   // of behind a barrier on it.
   const int done0 = lead ? P.state->done : 1;
   if (threadIdx.x == 0) *s_done = P.state->done;
-  pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1);
+  pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1, wt_rows);
   __syncthreads();
   if (*s_done) return;
   // (two nets: the two halves of the block pack them side by side)
@@ -902,8 +937,22 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
 // second-level partial rows, applies Adam to its own copy of theta and builds both operand images straight into its LDS
 // (all blocks compute the same bits); block 0 stores theta, the moments, the images and the theta-norm monitor — see
 // fwd2_theta_prologue.
+// gu_nb > 0 (the iteration graph, queue form only): this launch is also the DISPLACEMENT UPDATE of the previous iteration
+// (dL/du + Adam(u) + clamp: what k_node_gradu does, pf_node.h).  The block owns a contiguous run of node tasks (PF_GU_M x
+// 64 nodes each) beside its element tasks and its waves draw one of them after every `gu_every` element tasks: the node
+// tasks are three dependent round trips through memory with next to no arithmetic, the element tasks vector-issue bound —
+// the waves of a SIMD hide one behind the other, and the graph needs no side branch (no fork, no join: ~12 us per
+// iteration on MI355X) and no second displacement vector.  Each task's sum of u_free^2 lands in LDS at the task's index
+// and the block adds them in index order: the monitor does not depend on which wave drew what.  The block's sum goes to
+// partials[PF_PART_U2 + block]; entries up to gu_nb (what the bookkeeping sums: pf_node_blocks) are zeroed.  gu_k: the
+// stiffness records of the previous iteration (the half this launch does NOT write).
+#ifndef PF_GU_M
+#define PF_GU_M 2
+#endif
+#define PF_GU_MAX_TASKS 1024
 template <int NRE, int NRA, int L, int IN>
-__global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg, int s2_half, int queue) {
+__global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg, int s2_half, int queue, int gu_nb,
+                                                               const float* __restrict__ gu_k, int s1_rows) {
   using EE = Eng<NRE>;
   using EA = Eng<NRA>;
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
@@ -929,8 +978,12 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   const int rounds = (ntasks + per_round - 1) / per_round;
   const int per_block = (ntasks + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t0 = (int)blockIdx.x * per_block, t1 = min(t0 + per_block, ntasks);
-  __shared__ int s_next;
-  if (threadIdx.x == 0) s_next = waves;           // tasks t0 .. t0+waves-1 go to the waves in order, the rest through the queue
+  __shared__ int s_next, s_next_n;
+  __shared__ float s_u2[PF_GU_MAX_TASKS];
+  if (threadIdx.x == 0) {
+    s_next = waves;           // tasks t0 .. t0+waves-1 go to the waves in order, the rest through the queue
+    s_next_n = 0;
+  }
   int task = queue ? t0 + wv : (int)blockIdx.x * waves + wv;
   float xn[3];
   ElemGeo gn = ElemGeo{0.f, 0.f, 0.f, 1.f};
@@ -939,9 +992,66 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
     load_x<IN>(xn, P, e0);
     gn = load_geo(P.mesh.egeo, e0);
   }
+  // node tasks of this block (gu_nb > 0)
+  constexpr int GUN = 64 * PF_GU_M;
+  const int n_ntasks = gu_nb > 0 ? (P.mesh.n_nodes + GUN - 1) / GUN : 0;
+  const int npb = (n_ntasks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int nt0 = (int)blockIdx.x * npb, nn_b = max(min(nt0 + npb, n_ntasks) - nt0, 0);
+  const int gu_every = nn_b > 0 ? max((t1 - t0) / nn_b, 0) : 0;
+  bool gu = nn_b > 0;
+  int since = nn_b > 0 ? wv % (gu_every + 1) : 0;     // (the waves start out of phase)
+  GraduConsts GK = GraduConsts{0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (gu_nb > 0) GK = gradu_consts(P);
   __shared__ int s_done;
+  // one node task of the block's queue by the calling wave; false when the queue is empty
+  auto node_task = [&]() {
+    int k = 0;
+    if (lane == 0) k = atomicAdd(&s_next_n, 1);
+    k = __builtin_amdgcn_readfirstlane(k);
+    if (k >= nn_b) return false;
+    float su = node_gradu_task<IN - 1, PF_GU_M>(P, gu_k, GK, (nt0 + k) * GUN, lane);
+    su = pf_wave_sum(su);
+    if (lane == 0) s_u2[k] = su;
+    return true;
+  };
   if (s2_half >= 0) {
-    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done);
+    if (s1_rows > 0) {
+      // s1_rows > 0 (PF_FUSE_S1F=1, off by default: measured SLOWER on MI355X, 0.155 against 0.146 ms per iteration — the
+      // hand-off chain row sums -> write-through -> counter -> poll -> row loads is longer than the launch boundary it
+      // replaces, profiles/r03_ab.txt): the first level of the gradient-row reduction happens HERE (what k_theta_stage1 does, to the bit): the
+      // launch's first PF_RG blocks sum one row group each, store the second-level row write-through, drain, and count
+      // themselves in; every block then waits for the PF_RG arrivals before its update prologue reads the rows with
+      // agent-scope loads (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + drained counter add, one poll,
+      // workgroup barrier, sc1 loads).  The producers never wait for anything before they arrive and are the first blocks
+      // the dispatcher places, so the waiting blocks cannot keep them out; meanwhile every wave works on a node task.
+      // The stop flag is stable while this launch runs: all blocks take the same way out.
+      if (threadIdx.x == 0) s_done = P.state->done;
+      __syncthreads();
+      if (s_done) return;
+      int* hand = reinterpret_cast<int*>(P.partials + PF_PART_WG + ((size_t)P.n_part_blocks + PF_RG) * P.pad_total) + PF_RG;
+      int mine = 0;
+      for (int g = (int)blockIdx.x; g < PF_RG; g += (int)gridDim.x, ++mine) stage1_group(P, s1_rows, g, false, true);
+      if (mine) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's row stores have left
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(hand, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (gu) gu = node_task();
+      if (threadIdx.x == 0) {
+        while (__hip_atomic_load(hand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PF_RG) __builtin_amdgcn_s_sleep(16);
+      }
+      __syncthreads();
+    }
+    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done, s1_rows > 0);
+    if (s1_rows > 0 && threadIdx.x == 0) {
+      // every block has seen the counter full once it has passed here: the last one to pass zeroes both for the next launch
+      int* hand = reinterpret_cast<int*>(P.partials + PF_PART_WG + ((size_t)P.n_part_blocks + PF_RG) * P.pad_total) + PF_RG;
+      const int old = __hip_atomic_fetch_add(hand + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == (int)gridDim.x - 1) {
+        __hip_atomic_store(hand, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hand + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   } else {
     if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
@@ -949,7 +1059,15 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   if (s_done || n <= 0) return;
   const float bo_e = reinterpret_cast<const float*>(img_e + pf_n32_off_bo())[0];
   const float bo_a = reinterpret_cast<const float*>(img_a + pf_n32_off_bo())[0];
-  for (int r = 0; queue ? task < t1 : r < rounds; ++r) {
+  for (int r = 0; queue ? (task < t1 || gu) : r < rounds; ++r) {
+    if (gu && (since >= gu_every || task >= t1)) {
+      // a node task: the next element task's inputs (already on their way) are not touched
+      since = 0;
+      gu = node_task();
+      continue;
+    }
+    if (task >= t1) break;
+    ++since;
     if (grp == 0) __builtin_amdgcn_s_barrier();
     // the task after this one: drawn now (queue) so that its inputs travel while this one computes
     int nxt;
@@ -995,17 +1113,19 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
     if (grp == 3) __builtin_amdgcn_s_barrier();
     task = nxt;
   }
-}
-
-// Stores of a block's partial gradient row; wt: agent-scope write-through (global_store ... sc1).  With PF_FUSE_S1=1 the
-// fused backward launch hands the rows to the LAST block of each row group inside the launch (rows_reduce_last below), and a hand-off without a
-// release fence needs every handed-off byte stored this way (MI355X_MICROARCH.md, inter-workgroup visibility, valid forms).
-__device__ __forceinline__ void row_store(float* p, float v, bool wt) {
-  if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;                                       // (the usual case: the rows are read by the NEXT launch)
-}
-__device__ __forceinline__ float row_load(const float* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (gu_nb > 0) {
+    // the block's share of sum u_free^2, node tasks in index order (every wave's loop has ended: no return above this point
+    // once the stop flag was read)
+    __syncthreads();
+    float su = 0.f;
+    for (int i = threadIdx.x; i < nn_b; i += blockDim.x) su += s_u2[i];
+    float* red = reinterpret_cast<float*>(s_u2 + PF_GU_MAX_TASKS - 16);
+    __syncthreads();
+    su = pf_block_sum(su, red);
+    if (threadIdx.x == 0) P.partials[PF_PART_U2 + blockIdx.x] = su;
+    for (int j = (int)blockIdx.x + (int)gridDim.x + (int)threadIdx.x * (int)gridDim.x; j < gu_nb; j += (int)blockDim.x * (int)gridDim.x)
+      P.partials[PF_PART_U2 + j] = 0.f;
+  }
 }
 
 // First level of the parameter-gradient reduction INSIDE the backward launch (what the k_theta_stage1 launch does
@@ -1028,18 +1148,7 @@ __device__ __forceinline__ void rows_reduce_last(const pf_problem& P, int nb_row
   }
   __syncthreads();
   if (!s_last) return;
-  // the arithmetic of k_theta_stage1 for row group g: four interleaved row sums per column, combined (0 + 1) + (2 + 3)
-  float* __restrict__ out = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total + (size_t)g * P.pad_total;
-  for (int col = threadIdx.x; col < P.pad_total; col += blockDim.x) {
-    const float* rows = P.partials + PF_PART_WG + col;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0; r < r1; r += 4) {
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (r + k < r1) a[k] += row_load(rows + (size_t)(r + k) * P.pad_total);
-    }
-    out[col] = (a[0] + a[1]) + (a[2] + a[3]);
-  }
+  stage1_group(P, nb_rows, g, true, false);
 }
 
 // One net's backward over the block's tasks, as a phase of a launch: `smem` = this net's operand image in LDS (copied by
@@ -1349,31 +1458,32 @@ int launch_bwd_gea(const pf_problem* p, int which, hipStream_t s) { return launc
 
 // fused forward of both nets: the E net's bucket is this translation unit's PF_NR, the A net's bucket is dispatched here
 template <int NRA, int L, int IN>
-int launch_fwd2_t(const pf_problem* p, hipStream_t s, int s2_half) {
+int launch_fwd2_t(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o) {
+  const int s2_half = o.s2_half, gu_nb = o.gu_nb;
   constexpr int NRE = PF_NR;
   const int n = p->mesh.n_elems;
-  int nb = (n + FW_THREADS - 1) / FW_THREADS;
-  static const int cap = getenv("PF_FWD32_BLOCKS") ? atoi(getenv("PF_FWD32_BLOCKS")) : 256;   // one block per CU
-  if (nb > cap) nb = cap;
-  if (nb < 1) nb = 1;
+  const int nb = pf_n32_fwd2_blocks(n);
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;
   const size_t lds = 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255) + (s2_half < 0 ? 0 : (size_t)p->n_theta_active * sizeof(float));
   if (lds > 64000) { pf_set_error("too many trainable parameters for the fused theta update"); return PF_ERR_UNSUPPORTED; }
   // PF_FWD_QUEUE=0: experiment knob (round 2's lockstep rounds instead of the per-block task queue)
-  static const int queue = getenv("PF_FWD_QUEUE") ? atoi(getenv("PF_FWD_QUEUE")) : 1;
-  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half, queue);
+  static const int queue_knob = getenv("PF_FWD_QUEUE") ? atoi(getenv("PF_FWD_QUEUE")) : 1;
+  const int queue = gu_nb > 0 ? 1 : queue_knob;       // (the displacement update rides on the queue form only)
+  if (gu_nb > 0 && !pf_n32_fwd2_can_update_u(p, gu_nb)) { pf_set_error("fused forward: displacement update not possible on this problem"); return PF_ERR_UNSUPPORTED; }
+  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half, queue, gu_nb, o.gu_k,
+                     s2_half >= 0 ? o.s1_rows : 0);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>
-int launch_fwd2(const pf_problem* p, hipStream_t s, int s2_half) {
+int launch_fwd2(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o) {
   switch (pf_net32_bucket(p->net[1].width)) {
-    case 2: return launch_fwd2_t<2, L, IN>(p, s, s2_half);
-    case 4: return launch_fwd2_t<4, L, IN>(p, s, s2_half);
-    case 6: return launch_fwd2_t<6, L, IN>(p, s, s2_half);
-    case 8: return launch_fwd2_t<8, L, IN>(p, s, s2_half);
-    case 10: return launch_fwd2_t<10, L, IN>(p, s, s2_half);
-    case 12: return launch_fwd2_t<12, L, IN>(p, s, s2_half);
-    case 15: return launch_fwd2_t<15, L, IN>(p, s, s2_half);
+    case 2: return launch_fwd2_t<2, L, IN>(p, s, o);
+    case 4: return launch_fwd2_t<4, L, IN>(p, s, o);
+    case 6: return launch_fwd2_t<6, L, IN>(p, s, o);
+    case 8: return launch_fwd2_t<8, L, IN>(p, s, o);
+    case 10: return launch_fwd2_t<10, L, IN>(p, s, o);
+    case 12: return launch_fwd2_t<12, L, IN>(p, s, o);
+    case 15: return launch_fwd2_t<15, L, IN>(p, s, o);
   }
   pf_set_error("MFMA32 engine: area net width outside 1..30");
   return PF_ERR_UNSUPPORTED;
@@ -1460,16 +1570,16 @@ int PF_N32_SYM(backward_gea_)(const pf_problem* p, int which, hipStream_t s) {
 }
 #else
 // both nets enabled, same number of hidden layers and the same inputs (pf_api.hip checks): young net of THIS bucket
-int PF_N32_SYM(forward2_)(const pf_problem* p, hipStream_t s, int s2_half) {
+int PF_N32_SYM(forward2_)(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o) {
   const int L = p->net[0].n_hidden, IN = p->net[0].in_dim;
   if (IN == 3) {
-    if (L == 1) return launch_fwd2<1, 3>(p, s, s2_half);
-    if (L == 2) return launch_fwd2<2, 3>(p, s, s2_half);
-    if (L == 3) return launch_fwd2<3, 3>(p, s, s2_half);
+    if (L == 1) return launch_fwd2<1, 3>(p, s, o);
+    if (L == 2) return launch_fwd2<2, 3>(p, s, o);
+    if (L == 3) return launch_fwd2<3, 3>(p, s, o);
   } else if (IN == 2) {
-    if (L == 1) return launch_fwd2<1, 2>(p, s, s2_half);
-    if (L == 2) return launch_fwd2<2, 2>(p, s, s2_half);
-    if (L == 3) return launch_fwd2<3, 2>(p, s, s2_half);
+    if (L == 1) return launch_fwd2<1, 2>(p, s, o);
+    if (L == 2) return launch_fwd2<2, 2>(p, s, o);
+    if (L == 3) return launch_fwd2<3, 2>(p, s, o);
   }
   pf_set_error("net shape outside the compiled menu (in_dim 2|3, hidden layers 1..3)");
   return PF_ERR_UNSUPPORTED;

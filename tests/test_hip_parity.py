@@ -957,6 +957,17 @@ def test_bf16_mlp_hybrid_example_tolerance(ex):
 
 
 # ---- BASELINE-size checks of the product path ----------------------------------------------------
+
+
+def _assert_history_equal(a, b):
+    """Histories of the iteration graph and of eager launches: every column bit for bit, except the u-norm monitor
+    (column 3) — the graph's displacement update runs inside the forward launch and adds the block partials of
+    sum u_free^2 in another (fixed) grouping than the stand-alone kernel: same sum to float32 round-off."""
+    cols = [c for c in range(a.shape[1]) if c != 3]
+    assert np.array_equal(a[:, cols], b[:, cols])
+    assert np.allclose(a[:, 3], b[:, 3], rtol=2e-6, atol=0.0)
+
+
 def test_full_size_graph_equals_eager_bitwise():
     """10^6 elements, ex4 shape, default element-force formulation: 40 iterations replayed as the dependency-DAG
     hipGraph (the product path of bench.py) and the same 40 launched eagerly in stream order end in bit-identical
@@ -979,7 +990,7 @@ def test_full_size_graph_equals_eager_bitwise():
         del eng
     assert np.array_equal(outs[0][0], outs[1][0])
     assert np.array_equal(outs[0][1], outs[1][1])
-    assert np.array_equal(outs[0][2], outs[1][2])
+    _assert_history_equal(outs[0][2], outs[1][2])
     assert np.all(np.isfinite(outs[0][2])) and outs[0][2][-1, 0] < outs[0][2][0, 0]      # and the loss went down
 
 
@@ -997,7 +1008,7 @@ def test_graph_stop_in_mid_replay_equals_eager(max_it, tol, expect):
         model, mv, md, _ = build_model(250_000, "ex4")
         cfg = SolverConfig(max_iterations=max_it, tolerance=tol, learning_rate_u=0.01, learning_rate_theta=5e-4)
         eng = HipEngine(model, mv, md)
-        assert eng.fusion_info() == 15                     # every fused form is active on this problem
+        assert eng.fusion_info() == 1 + 2 + 4 + 16              # every fused form is active on this problem
         eng.begin(None, 0.1, cfg, want_history=True)
         eng.iterate(2 * eng.GRAPH_ITERS, use_graph=use_graph)
         torch.cuda.synchronize()
@@ -1008,8 +1019,9 @@ def test_graph_stop_in_mid_replay_equals_eager(max_it, tol, expect):
         # the nets' operand images belong to the final theta: a property evaluation from the stored images (no re-pack)
         # equals one after re-packing
         del eng
-    for a, b in zip(outs[0], outs[1]):
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):
         assert np.array_equal(a, b)
+    _assert_history_equal(outs[0][-1], outs[1][-1])
 
 
 def test_full_size_loss_and_grads_vs_oracle_prefix():
@@ -1195,7 +1207,8 @@ def test_beyond_infinity_cache_1e7_elements():
         assert eng.state().iter == eng.GRAPH_ITERS
         outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.history(eng.GRAPH_ITERS).copy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
-    assert np.array_equal(outs[0][2], outs[1][2]) and np.all(np.isfinite(outs[0][2]))
+    _assert_history_equal(outs[0][2], outs[1][2])
+    assert np.all(np.isfinite(outs[0][2]))
     # (1) equilibrium of the element forces at a smooth displacement field
     x = np.arange(n + 1, dtype=np.float64)
     u = np.zeros(2 * (n + 1), dtype=np.float32)
