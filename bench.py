@@ -484,7 +484,6 @@ def main():
                                "theta_update_in_next_forward (graph)": bool(fused & _capi.PF_FUSED_THETA_UPDATE),
                                "displacement_ping_pong (graph)": bool(fused & _capi.PF_FUSED_U_PINGPONG),
                                "displacement_update_in_next_forward (graph)": bool(fused & _capi.PF_FUSED_U_UPDATE),
-                               "gradient_row_reduction_in_next_forward (graph)": bool(fused & _capi.PF_FUSED_ROW_REDUCTION),
                                "note": "a fused launch is booked on the first of its two kernel_ms slots"},
             "roofline": roof,
         }

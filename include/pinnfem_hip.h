@@ -224,15 +224,13 @@ long long pf_partials_count(const pf_problem* p);
  * is ONE launch, 2 both backward passes (with the element adjoint) are ONE two-phase launch, 4 the iteration graph folds
  * the parameter update into the next forward launch, 8 the iteration graph ping-pongs two displacement vectors (the
  * displacement update on a side branch), 16 the iteration graph folds the displacement update (dL/du + Adam(u) + clamp)
- * into the next forward launch as well (8 and 16 exclude each other), 32 the first level of the gradient-row reduction
- * runs inside that forward launch too: the graph is then ONE chain of three launches per iteration.  In the
+ * into the next forward launch as well and is ONE chain of four launches per iteration (8 and 16 exclude each other).  In the
  * per-slot times of pf_gd_iterations_timed a fused launch is booked on the FIRST of its two slots. */
 #define PF_FUSED_FORWARD 1
 #define PF_FUSED_BACKWARD 2
 #define PF_FUSED_THETA_UPDATE 4
 #define PF_FUSED_U_PINGPONG 8
 #define PF_FUSED_U_UPDATE 16
-#define PF_FUSED_ROW_REDUCTION 32
 int pf_fusion_info(const pf_problem* p);
 
 /* ---- building blocks (each replaces the cited reference lines) ------------------------ */

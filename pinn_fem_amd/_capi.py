@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpinnfem_hip.so")
+# PINNFEM_LIB: another build of the same library (experiment builds, A/B runs); no fallback of any kind
+LIB_PATH = os.environ.get("PINNFEM_LIB") or os.path.join(_HERE, "lib", "libpinnfem_hip.so")
 
 PF_ABI_VERSION = 7
 PF_OK, PF_ERR_ARG, PF_ERR_UNSUPPORTED, PF_ERR_HIP = 0, -1, -2, -3
@@ -25,7 +26,6 @@ PF_MAX_NODE_BLOCKS = 4096
 PF_NODE_SLOTS = PF_MAX_NODE_BLOCKS + 8
 PF_KERNEL_SLOTS = 9
 PF_FUSED_FORWARD, PF_FUSED_BACKWARD, PF_FUSED_THETA_UPDATE, PF_FUSED_U_PINGPONG, PF_FUSED_U_UPDATE = 1, 2, 4, 8, 16
-PF_FUSED_ROW_REDUCTION = 32
 KERNEL_SLOT_NAMES = ("net_forward_young", "net_forward_area", "node_residual", "elem_adjoint",
                      "net_backward_young", "net_backward_area", "node_gradu_adam", "theta_reduce_adam",
                      "finalize")

@@ -29,7 +29,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.j
 
 
 def _sources():
-    units = [("pf_api.o", "pf_api.hip", []), ("pf_mesh.o", "pf_mesh.hip", ["-fno-slp-vectorize"]),
+    # experiment build: nodes per lane of a node task inside the fused forward launch (pf_net32.h: PF_GU_M)
+    gu = ["-DPF_GU_M=" + str(int(os.environ["PINNFEM_GU_M"]))] if os.environ.get("PINNFEM_GU_M") else []
+    units = [("pf_api.o", "pf_api.hip", gu), ("pf_mesh.o", "pf_mesh.hip", ["-fno-slp-vectorize"]),
              ("pf_comm.o", "pf_comm.hip", []), ("pf_pcg.o", "pf_pcg.hip", [])]
     # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
     # removes the v_accvgpr_read copies in front of every tanh
@@ -39,7 +41,7 @@ def _sources():
     # v_pk_mul_f32, which issue SLOWER than the two scalar instructions they replace on gfx950 (6.6 against 2 x 1.4 cycles
     # per SIMD, tools/valu_rate2.hip) and need register-pair shuffling on top (100 v_mov per 64 elements in the forward
     # kernel, 31 without); registers per lane drop from 108 to 95
-    n32 = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+    n32 = ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + gu
     if os.environ.get("PINNFEM_N32_DBG", "0") == "1":       # timing-experiment build: the PF_N32_DBG knobs are live
         n32.append("-DPF_N32_DBG_ENABLE=1")
     if os.environ.get("PINNFEM_N32_NOPIPE", "0") == "1":    # experiment build: hidden layers as [all MFMAs][all tanh stages]

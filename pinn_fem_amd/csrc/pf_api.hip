@@ -168,7 +168,7 @@ static int net_forward2(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& 
 }
 // the forward pass of every enabled net: the properties and, with the MFMA32 engine, the stiffness records.
 // s2_half >= 0: the FIRST launch also runs the parameter update of the previous iteration (can_fuse_theta_update)
-// o.gu_nb / o.s1_rows (only with can_fuse_gradu / can_fuse_stage1; fused launch only): see pf_fwd2_opts
+// o.gu_nb (only with can_fuse_gradu; fused launch only): see pf_fwd2_opts
 static int net_forward_all(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o = pf_fwd2_opts()) {
   if (can_fuse_forward(p)) return net_forward2(p, s, o);
   int s2_half = o.s2_half;
@@ -186,15 +186,6 @@ static bool can_fuse_theta_update(const pf_problem* p) {
   static const int knob = getenv("PF_FUSE_S2") ? atoi(getenv("PF_FUSE_S2")) : 1;
   return knob != 0 && p->wg_mode == PF_WG_MFMA32 && p->theta_alt != nullptr && p->n_theta_active > 0 &&
          (p->net[0].enabled || p->net[1].enabled);
-}
-
-// Can the fused forward launch that carries the parameter update also do the first level of the gradient-row reduction
-// (k_theta_stage1's work: its first PF_RG blocks sum one row group each and hand the second-level rows to every block of
-// the launch through write-through stores and a counter)?  One launch and one boundary less per iteration.
-// PF_FUSE_S1F=0: experiment knob (stand-alone theta stage 1 launch).
-static bool can_fuse_stage1(const pf_problem* p) {
-  static const int knob = getenv("PF_FUSE_S1F") ? atoi(getenv("PF_FUSE_S1F")) : 1;
-  return knob != 0 && can_fuse_forward(p) && can_fuse_theta_update(p);
 }
 
 // Can the iteration graph fold the displacement update (dL/du + Adam(u) + clamp) of iteration t into the fused forward
@@ -336,7 +327,6 @@ int pf_fusion_info(const pf_problem* p) {
   if (can_fuse_backward(p)) m |= PF_FUSED_BACKWARD;
   if (can_fuse_theta_update(p)) m |= PF_FUSED_THETA_UPDATE;
   if (p->prop_double != 0 && p->elem_k != nullptr && can_fuse_gradu(p)) m |= PF_FUSED_U_UPDATE;
-  if (can_fuse_stage1(p)) m |= PF_FUSED_ROW_REDUCTION;
   else if (p->u_alt != nullptr && p->mesh.n_elems >= PF_GRAPH_DAG_MIN_ELEMS) m |= PF_FUSED_U_PINGPONG;
   return m;
 }
@@ -577,9 +567,6 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
   // ping-pongs between its two halves so that block 0's stores never meet another block's loads.  Only the replay's
   // last iteration keeps the stand-alone update, which also brings the state back to half 0.
   const bool fuse_s2 = can_fuse_theta_update(p);
-  // ... and the first reduction level of the gradient rows with it (can_fuse_stage1): the chain of an iteration is then
-  // forward (+ both updates of the previous iteration) -> residual (+ bookkeeping) -> backward
-  const bool fuse_s1f = fuse_s2 && can_fuse_stage1(p) && !fuse_s1_knob();
   // Displacement vectors ping-pong too (pf_problem.u_alt; DAG form, even replay length): the update of iteration i reads
   // U[i & 1] like the residual and the element adjoint of i and WRITES U[(i + 1) & 1], so it forks right behind the
   // residual and runs beside the whole backward launch.  PF_GRAPH_UPP=0: experiment knob (in place, fork behind the
@@ -613,10 +600,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     const float* k_prev = nullptr;        // the records iteration i-1 wrote (the other half)
     if (fuse_gu && i > 0) k_prev = ((i - 1) & 1) ? c_elem_k + (size_t)q.mesh.n_elems * (q.mesh.dim == 2 ? 3 : 1) : c_elem_k;
     pf_fwd2_opts fo;
-    if (fuse_s2 && i > 0) {
-      fo.s2_half = (i - 1) & 1;
-      if (fuse_s1f) fo.s1_rows = pf_net_blocks(p);      // (no stand-alone stage 1 behind the backward of i-1)
-    }
+    if (fuse_s2 && i > 0) fo.s2_half = (i - 1) & 1;
     if (k_prev) {
       fo.gu_nb = pf_node_blocks(q.mesh.n_nodes);
       fo.gu_k = k_prev;
@@ -642,8 +626,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
         if (!upp && fuse_gea && k == first && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");
       }
     }
-    if (!(can_fuse_backward(p) && fuse_s1_knob()) && !(fuse_s1f && i < iters - 1))
-      PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
+    if (!(can_fuse_backward(p) && fuse_s1_knob())) PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
     if (!fuse_s2 || i == iters - 1) PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
     // branch A (created after the main chain's nodes of this iteration): gradu behind the last reader of u
     if (fuse_gu && i < iters - 1) continue;           // (the next forward launch carries it)

@@ -124,10 +124,8 @@ __device__ __forceinline__ float* pf_theta_half_ptr(const pf_problem& P, int hal
 // when non-null.  The state is read from half `half_in` and stored to half `half_out` (0, 0: in place).
 // skip_stores: compute only (the block-uniform stop flag as loaded by the caller — the loads below are then issued WITH
 // that load instead of behind a branch on it; or a block of the forward launch that only needs its own copy).
-// wt_loads: the second-level rows were stored write-through by OTHER blocks of this very launch (pf_net32.hip:
-// stage1_group inside the forward launch): read them with agent-scope (sc1) loads, behind the caller's poll + barrier.
 __device__ __forceinline__ void pf_theta_update(const pf_problem& P, int fuse_adam, float* new_theta, int skip_stores = 0,
-                                                int half_in = 0, int half_out = 0, bool wt_loads = false) {
+                                                int half_in = 0, int half_out = 0) {
   PF_NO_CONTRACT
   const float* __restrict__ p2 = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total;
   const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
@@ -146,10 +144,7 @@ __device__ __forceinline__ void pf_theta_update(const pf_problem& P, int fuse_ad
     if (fuse_adam) { m = m_i[q]; v = v_i[q]; }
     float g = 0.f;
 #pragma unroll
-    for (int r = 0; r < PF_RG; ++r) {
-      const float* src = p2 + (size_t)r * P.pad_total + pi;
-      g += wt_loads ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
-    }
+    for (int r = 0; r < PF_RG; ++r) g += p2[(size_t)r * P.pad_total + pi];
     if (fuse_adam) {
       m = m + b1w * (g - m);
       v = v * b2;
@@ -378,12 +373,10 @@ PF_DECL_NET_LAUNCHERS(32)
 
 // What a fused forward launch (pf_net32.hip: k_net32_forward2) does besides the two forward passes (the iteration graph):
 //   s2_half >= 0  the parameter update of the previous iteration from that state half (fwd_theta_prologue)
-//   s1_rows > 0   ... and the first level of its gradient-row reduction (what k_theta_stage1 does for s1_rows rows)
 //   gu_nb > 0     the displacement update of the previous iteration (pf_node.h) reading the stiffness records gu_k; gu_nb =
 //                 entries of the u-norm partial sums the bookkeeping reads
 struct pf_fwd2_opts {
   int s2_half = -1;
-  int s1_rows = 0;
   int gu_nb = 0;
   const float* gu_k = nullptr;
 };

@@ -795,15 +795,14 @@ __device__ __forceinline__ void stage1_group(const pf_problem& P, int nb_rows, i
 // also stores the new state into the other half, the images (with the backward's scaling bound) and the theta-norm
 // monitor to global memory and flips state->theta_half: nothing any block of this launch reads.  Two block barriers.
 __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half_in, unsigned char* img_lds0,
-                                                   unsigned char* img_lds1, float* new_theta, int img_bytes, int* s_done,
-                                                   bool wt_rows = false) {
+                                                   unsigned char* img_lds1, float* new_theta, int img_bytes, int* s_done) {
   const bool lead = blockIdx.x == 0;
   // The stop flag is stable while a forward launch runs (the bookkeeping that raises it is ordered behind it), so the lead
   // block may read it for itself, and every block's update loads leave together with the block's one flag read instead
   // of behind a barrier on it.
   const int done0 = lead ? P.state->done : 1;
   if (threadIdx.x == 0) *s_done = P.state->done;
-  pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1, wt_rows);
+  pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1);
   __syncthreads();
   if (*s_done) return;
   // (two nets: the two halves of the block pack them side by side)
@@ -952,7 +951,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
 #define PF_GU_MAX_TASKS 1024
 template <int NRE, int NRA, int L, int IN>
 __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg, int s2_half, int queue, int gu_nb,
-                                                               const float* __restrict__ gu_k, int s1_rows) {
+                                                               const float* __restrict__ gu_k) {
   using EE = Eng<NRE>;
   using EA = Eng<NRA>;
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
@@ -1000,8 +999,6 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   const int gu_every = nn_b > 0 ? max((t1 - t0) / nn_b, 0) : 0;
   bool gu = nn_b > 0;
   int since = nn_b > 0 ? wv % (gu_every + 1) : 0;     // (the waves start out of phase)
-  GraduConsts GK = GraduConsts{0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (gu_nb > 0) GK = gradu_consts(P);
   __shared__ int s_done;
   // one node task of the block's queue by the calling wave; false when the queue is empty
   auto node_task = [&]() {
@@ -1009,49 +1006,21 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
     if (lane == 0) k = atomicAdd(&s_next_n, 1);
     k = __builtin_amdgcn_readfirstlane(k);
     if (k >= nn_b) return false;
-    float su = node_gradu_task<IN - 1, PF_GU_M>(P, gu_k, GK, (nt0 + k) * GUN, lane);
+    // what the task needs of the problem is read from the kernel argument HERE (P is the first argument: offset 0 of the
+    // kernarg segment), behind an opaque move: left to the compiler, every pointer is loaded once at the top of the launch
+    // and the element loop spills scalar registers (75 against 7 without the node tasks)
+    const __attribute__((address_space(4))) pf_problem* pk =
+        (const __attribute__((address_space(4))) pf_problem*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pk));
+    const NodeView NV = node_view_from(pk);
+    const GraduConsts GK = gradu_consts_from(pk);
+    float su = node_gradu_task<IN - 1, PF_GU_M>(NV, gu_k, GK, (nt0 + k) * GUN, lane);
     su = pf_wave_sum(su);
     if (lane == 0) s_u2[k] = su;
     return true;
   };
   if (s2_half >= 0) {
-    if (s1_rows > 0) {
-      // s1_rows > 0 (PF_FUSE_S1F=1, off by default: measured SLOWER on MI355X, 0.155 against 0.146 ms per iteration — the
-      // hand-off chain row sums -> write-through -> counter -> poll -> row loads is longer than the launch boundary it
-      // replaces, profiles/r03_ab.txt): the first level of the gradient-row reduction happens HERE (what k_theta_stage1 does, to the bit): the
-      // launch's first PF_RG blocks sum one row group each, store the second-level row write-through, drain, and count
-      // themselves in; every block then waits for the PF_RG arrivals before its update prologue reads the rows with
-      // agent-scope loads (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores + drained counter add, one poll,
-      // workgroup barrier, sc1 loads).  The producers never wait for anything before they arrive and are the first blocks
-      // the dispatcher places, so the waiting blocks cannot keep them out; meanwhile every wave works on a node task.
-      // The stop flag is stable while this launch runs: all blocks take the same way out.
-      if (threadIdx.x == 0) s_done = P.state->done;
-      __syncthreads();
-      if (s_done) return;
-      int* hand = reinterpret_cast<int*>(P.partials + PF_PART_WG + ((size_t)P.n_part_blocks + PF_RG) * P.pad_total) + PF_RG;
-      int mine = 0;
-      for (int g = (int)blockIdx.x; g < PF_RG; g += (int)gridDim.x, ++mine) stage1_group(P, s1_rows, g, false, true);
-      if (mine) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's row stores have left
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(hand, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (gu) gu = node_task();
-      if (threadIdx.x == 0) {
-        while (__hip_atomic_load(hand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < PF_RG) __builtin_amdgcn_s_sleep(16);
-      }
-      __syncthreads();
-    }
-    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done, s1_rows > 0);
-    if (s1_rows > 0 && threadIdx.x == 0) {
-      // every block has seen the counter full once it has passed here: the last one to pass zeroes both for the next launch
-      int* hand = reinterpret_cast<int*>(P.partials + PF_PART_WG + ((size_t)P.n_part_blocks + PF_RG) * P.pad_total) + PF_RG;
-      const int old = __hip_atomic_fetch_add(hand + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (old == (int)gridDim.x - 1) {
-        __hip_atomic_store(hand, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(hand + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
+    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done);
   } else {
     if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
@@ -1470,8 +1439,7 @@ int launch_fwd2_t(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o) {
   static const int queue_knob = getenv("PF_FWD_QUEUE") ? atoi(getenv("PF_FWD_QUEUE")) : 1;
   const int queue = gu_nb > 0 ? 1 : queue_knob;       // (the displacement update rides on the queue form only)
   if (gu_nb > 0 && !pf_n32_fwd2_can_update_u(p, gu_nb)) { pf_set_error("fused forward: displacement update not possible on this problem"); return PF_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half, queue, gu_nb, o.gu_k,
-                     s2_half >= 0 ? o.s1_rows : 0);
+  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half, queue, gu_nb, o.gu_k);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>

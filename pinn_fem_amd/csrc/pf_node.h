@@ -10,16 +10,50 @@
 
 struct GraduConsts { float step_size, bc2s, b1w, b2, b2w, eps, dcoef; };
 
-__device__ __forceinline__ GraduConsts gradu_consts(const pf_problem& P) {
+// PP: pointer to a pf_problem in any address space (the fused forward launch reads its own kernel argument through the
+// kernarg segment pointer, so that these values are loaded where a node task starts instead of living in scalar registers
+// over the whole launch)
+template <class PP>
+__device__ __forceinline__ GraduConsts gradu_consts_from(PP p) {
   GraduConsts K;
-  K.step_size = P.state->step_size_u;
-  K.bc2s = P.state->bc2_sqrt;
-  K.b1w = (float)(1.0 - P.beta1);
-  K.b2 = (float)P.beta2;
-  K.b2w = (float)(1.0 - P.beta2);
-  K.eps = (float)P.eps;
-  K.dcoef = P.n_meas_f > 0.f ? P.alpha_data / P.n_meas_f : 0.f;  // mean backward
+  const pf_state* st = p->state;
+  K.step_size = st->step_size_u;
+  K.bc2s = st->bc2_sqrt;
+  K.b1w = (float)(1.0 - p->beta1);
+  K.b2 = (float)p->beta2;
+  K.b2w = (float)(1.0 - p->beta2);
+  K.eps = (float)p->eps;
+  const float nm = p->n_meas_f;
+  K.dcoef = nm > 0.f ? p->alpha_data / nm : 0.f;  // mean backward
   return K;
+}
+__device__ __forceinline__ GraduConsts gradu_consts(const pf_problem& P) { return gradu_consts_from(&P); }
+
+// what a node task reads of the problem
+struct NodeView {
+  const int32_t *adj_ptr, *adj, *adj_other;
+  const uint8_t* dof_flags;
+  const float *meas_val, *g_f;
+  float *u, *m_u, *v_u, *grad_u;
+  int n_nodes, use_data, fe_mode;
+};
+template <class PP>
+__device__ __forceinline__ NodeView node_view_from(PP p) {
+  NodeView V;
+  V.adj_ptr = p->mesh.adj_ptr;
+  V.adj = p->mesh.adj;
+  V.adj_other = p->adj_other;
+  V.dof_flags = p->mesh.dof_flags;
+  V.meas_val = p->mesh.meas_val;
+  V.g_f = p->g_f;
+  V.u = p->u;
+  V.m_u = p->m_u;
+  V.v_u = p->v_u;
+  V.grad_u = p->grad_u;
+  V.n_nodes = p->mesh.n_nodes;
+  V.use_data = p->use_data;
+  V.fe_mode = p->fe_mode;
+  return V;
 }
 
 // dL/du of one dof: the gathered K^T g_f entry + d(alpha_d * mean d^2)/du where the dof is measured
@@ -52,28 +86,27 @@ __device__ __forceinline__ void dof_adam_u(const GraduConsts& K, float gu, float
 // Needs pf_problem.adj_other; single-GPU meshes only (no ghost elements, no shared dofs).  Accumulation in ascending
 // element id like gather_kv (pf_mesh.hip), same ke_rows_times: same bits.
 template <int DIM, int M>
-__device__ __forceinline__ float node_gradu_task(const pf_problem& P, const float* __restrict__ elem_k, const GraduConsts& K,
+__device__ __forceinline__ float node_gradu_task(const NodeView& P, const float* __restrict__ elem_k, const GraduConsts& K,
                                                  int node0, int lane) {
-  const pf_mesh& Ms = P.mesh;
-  const int nn = Ms.n_nodes;
+  const int nn = P.n_nodes;
   int node[M], b[M], e_[M];
   bool ok[M];
   float vs[M][2], acc[M][2], uo[M][2], meas[M][2];
   unsigned fl[M][2];
-  const float* __restrict__ mvals = P.use_data ? Ms.meas_val : P.u;     // (a select, not a branch: never read without use_data)
+  const float* __restrict__ mvals = P.use_data ? P.meas_val : P.u;     // (a select, not a branch: never read without use_data)
   // level 1: CSR row, the node's own values
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int n_ = node0 + m * 64 + lane;
     ok[m] = n_ < nn;
     node[m] = ok[m] ? n_ : nn - 1;
-    b[m] = Ms.adj_ptr[node[m]];
-    e_[m] = Ms.adj_ptr[node[m] + 1];
+    b[m] = P.adj_ptr[node[m]];
+    e_[m] = P.adj_ptr[node[m] + 1];
     load_vec<DIM>(P.g_f, node[m], vs[m]);
     load_vec<DIM>(P.u, node[m], uo[m]);
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
-      fl[m][c] = Ms.dof_flags[node[m] * DIM + c];
+      fl[m][c] = P.dof_flags[node[m] * DIM + c];
       meas[m][c] = mvals[node[m] * DIM + c];
       acc[m][c] = 0.f;
     }
@@ -99,9 +132,9 @@ __device__ __forceinline__ float node_gradu_task(const pf_problem& P, const floa
       has[m] = idx < e_[m];
       two[m] = idx + 1 < e_[m];
       const int i0 = has[m] ? idx : 0, i1 = two[m] ? idx + 1 : i0;
-      code0[m] = Ms.adj[i0];
+      code0[m] = P.adj[i0];
       oth0[m] = P.adj_other[i0];
-      code1[m] = Ms.adj[i1];
+      code1[m] = P.adj[i1];
       oth1[m] = P.adj_other[i1];
     }
     ElemK k0[M], k1[M];
