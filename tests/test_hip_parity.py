@@ -994,6 +994,52 @@ def test_full_size_graph_equals_eager_bitwise():
     assert np.all(np.isfinite(outs[0][2])) and outs[0][2][-1, 0] < outs[0][2][0, 0]      # and the loss went down
 
 
+@pytest.mark.parametrize("mesh,n,fe", [("chain", 3000, 0), ("chain", 60_000, 1), ("warren", 60_000, 0), ("warren", 250_000, 1),
+                                       ("bar1d", 70_001, 0), ("bar1d", 70_001, 1)])
+def test_graph_equals_eager_meshes(mesh, n, fe):
+    """The iteration graph runs the displacement update of iteration t-1 as node tasks INSIDE the forward launch of t
+    (pf_node.h: 2 x 64 nodes per task, the gather rewritten with all loads of a level in flight); the eager launches use
+    k_node_gradu.  Same bits in u, theta, the Adam moments and every history column but the u-norm, on: a chain with 3
+    forward blocks, the Warren girder (node degree 4: two gather rounds per node), a 1-D bar (one dof per node, 4-byte
+    stiffness records, net input [load_factor, x]), element forces in the reference and in the difference form."""
+    from bench import build_model
+    from pinn_fem_amd.engine import HipEngine
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.properties import NNProperty
+    from pinn_fem_amd.fem.solver import SolverConfig
+    from pinn_fem_amd.nets import SimpleNN
+    outs = []
+    for use_graph in (True, False):
+        if mesh == "bar1d":
+            rng = np.random.default_rng(11)
+            torch.manual_seed(5)
+            nodes = np.concatenate([[0.0], np.cumsum(rng.uniform(0.5, 1.5, n))]) * (3.0 / n)
+            elements = np.stack([np.arange(n), np.arange(1, n + 1)], 1)
+            loads = rng.normal(size=n + 1) * 0.1
+            md = rng.choice(np.arange(1, n + 1), size=n // 7, replace=False)
+            mv = rng.normal(size=len(md)) * 0.02
+            model = FEMModel(nodes, elements, Material(NNProperty(SimpleNN(2, 20, 2), 2, True, 1.5),
+                                                       NNProperty(SimpleNN(2, 15, 2), 2, True, 0.7)),
+                             loads, np.array([0]), dimension=1)
+        else:
+            model, mv, md, _ = build_model(n, "ex4", mesh=mesh)
+        cfg = SolverConfig(max_iterations=60, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
+        eng = HipEngine(model, mv, md, fe_mode=fe)
+        assert eng.fusion_info() & 16                           # the displacement update rides in the forward launch
+        eng.begin(None, 0.1, cfg, want_history=True)
+        n_it = 2 * eng.GRAPH_ITERS + 3                          # two whole replays and a part of one
+        eng.iterate(n_it, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert eng.state().iter == n_it
+        outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.m_u.cpu().numpy().copy(),
+                     eng.v_u.cpu().numpy().copy(), eng.m_t.cpu().numpy().copy(), eng.history(n_it).copy()))
+        del eng
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):
+        assert np.array_equal(a, b)
+    _assert_history_equal(outs[0][-1], outs[1][-1])
+    assert np.all(np.isfinite(outs[0][-1]))
+
+
 @pytest.mark.parametrize("max_it,tol,expect", [(40, 1e30, 12), (13, 0.0, 13), (15, 0.0, 15)])
 def test_graph_stop_in_mid_replay_equals_eager(max_it, tol, expect):
     """The iteration graph ping-pongs the displacement vector and the parameter state between two halves; a stop raised
