@@ -210,6 +210,21 @@ struct TaskIn {
   float ui[2], uj[2], gi[2], gj[2];
 };
 
+// 1 - e^(-s) for s >= 0 (softplus'(z) = sigmoid(z) from s = softplus(z)) to ~3 ulp in 11 instructions: the hardware exp2
+// where 1 - t does not cancel (s > 0.25: t < 0.78), the Taylor polynomial below it (next term s^8 / 8! < 4e-10 relative).
+// (libm's expm1f: ~25 instructions with a division, once per element and net in the backward's task head.)
+__device__ __forceinline__ float one_minus_exp_neg(float s) {
+  const float big = 1.0f - __builtin_amdgcn_exp2f(s * -1.4426950408889634f);
+  float p = 1.0f / 5040.0f;
+  p = fmaf(p, s, -1.0f / 720.0f);
+  p = fmaf(p, s, 1.0f / 120.0f);
+  p = fmaf(p, s, -1.0f / 24.0f);
+  p = fmaf(p, s, 1.0f / 6.0f);
+  p = fmaf(p, s, -0.5f);
+  p = fmaf(p, s, 1.0f);
+  return s > 0.25f ? big : p * s;
+}
+
 // with_nn: also load the element's node ids (the main loop has them already: they are fetched TWO tasks ahead, so that
 // the nodal gathers of task_fetch_b, which need them as addresses, never wait for a load issued in the same iteration)
 template <int IN, bool GEA>
@@ -1180,16 +1195,6 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
     const bool live = e < n;
     const TaskIn<DIM> cur = nxt;
     const bool more = base + stride < n;
-    if (more) {
-      // the next task's inputs: its node ids are already here, so its nodal gathers leave in the same breath; the ids
-      // of the task after it start their trip now
-      task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(e + stride, n - 1), false);
-      if (GEA) {
-        nxt.nn = nn_ahead;
-        task_fetch_b<IN, GEA>(nxt, P);
-        nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(e + 2 * stride, n - 1)];
-      }
-    }
     // ---- per-element scalars: one element per lane ----------------------------------------------------------
     // softplus'(z) = sigmoid(z) = 1 - exp(-softplus(z)) from the forward's stored value (= softplus(z) * scale), so the
     // output unit need not be recomputed (torch: z > 20 ? 1 : e^z / (e^z + 1), the same number to float round-off)
@@ -1204,7 +1209,7 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
       }
       float g = gea * cur.oth;   // mul backward of young*area        (nn_assembly.py:74)
       g = g * net.scale;         // output*scale backward              (properties.py:156)
-      gz = net.positive ? g * (-expm1f(-(cur.own * inv_scale))) : g;
+      gz = net.positive ? g * one_minus_exp_neg(cur.own * inv_scale) : g;
     }
     // power-of-two scale: max |d| S <= 2^14 with the weight bound of the image header; S only ever falls, T follows
     {
@@ -1231,6 +1236,19 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
     float xa0, xa1, xb0, xb1;
     both_tiles(cur.x[1], xa0, xa1);
     both_tiles(cur.x[2], xb0, xb1);
+    const float lam_in = cur.x[0];
+    if (more) {
+      // The next task's inputs leave HERE, behind the last use of this task's record (everything above consumed it: the
+      // tiles below work on derived values only), so the new values can land in the registers the old ones held — issued
+      // at the top of the task they needed a second set and a 19-register copy per task.  Its node ids are already here
+      // (fetched two tasks ahead), so its nodal gathers leave in the same breath; the ids of the task after it start now.
+      task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(e + stride, n - 1), false);
+      if (GEA) {
+        nxt.nn = nn_ahead;
+        task_fetch_b<IN, GEA>(nxt, P);
+        nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(e + 2 * stride, n - 1)];
+      }
+    }
     // ---- the two tiles ------------------------------------------------------------------------------------------
     auto tile_backward = [&](const typename E::template TileAct<L, true>& A, const float (&xt)[3], float gt) {
       // inputs of the combined tile: (kl lam, kx x, kx y, 1) resp. (kl lam, kx x, 1, 0)
@@ -1243,7 +1261,7 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
       if (!(dbg & 2)) E::template backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, wb, rd, dbg);
     };
     if constexpr (E::template bw_pair<L>()) {   // recompute both tiles together, then the two back-propagations (see bw_pair)
-      const float x0[3] = {cur.x[0], xa0, xb0}, x1[3] = {cur.x[0], xa1, xb1};
+      const float x0[3] = {lam_in, xa0, xb0}, x1[3] = {lam_in, xa1, xb1};
       typename E::template TileAct<L, true> A0, A1;
       float p0, p1;
       E::template forward_tiles<L, IN, true>(smem, lane, x0, x1, A0, A1, p0, p1);
@@ -1252,7 +1270,7 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
     } else {
       sfor<0, 2>([&](auto tt) {
         constexpr int TT = tt;
-        const float xt[3] = {cur.x[0], TT ? xa1 : xa0, TT ? xb1 : xb0};
+        const float xt[3] = {lam_in, TT ? xa1 : xa0, TT ? xb1 : xb0};
         typename E::template TileAct<L, true> A;
         E::template recompute_tile<L, IN>(smem, lane, xt, A);
         tile_backward(A, xt, TT ? g1 : g0);
