@@ -1212,8 +1212,13 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
       gz = net.positive ? g * one_minus_exp_neg(cur.own * inv_scale) : g;
     }
     // power-of-two scale: max |d| S <= 2^14 with the weight bound of the image header; S only ever falls, T follows
-    {
-      const float gmax = wave_max(fabsf(gz)) * bound;
+    // The wave-wide maximum (seven DPP steps) is only formed when it can change something: S = 2^(14 - ex) with
+    // gmax = m 2^ex, 0.5 <= m < 1, is smaller than the running S exactly when gmax * Srun >= 2^14, and a maximum passes
+    // that test iff one lane does (Srun is a power of two: the products are exact) — one multiply, one compare and a vote
+    // per task instead.
+    const float gabs = fabsf(gz) * bound;
+    if (Srun == 0.f || __builtin_amdgcn_ballot_w64(gabs * Srun >= 16384.0f) != 0ull) {
+      const float gmax = wave_max(gabs);
       if (gmax > 0.f && gmax < 3.0e38f) {
         int ex = 0;
         (void)frexpf(gmax, &ex);
