@@ -171,7 +171,7 @@ static int net_forward2(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& 
 // o.gu_nb (only with can_fuse_gradu; fused launch only): see pf_fwd2_opts
 static int net_forward_all(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o = pf_fwd2_opts()) {
   if (can_fuse_forward(p)) return net_forward2(p, s, o);
-  int s2_half = o.s2_half;
+  int s2_half = o.s2_half >= 0 && o.calc_index ? o.s2_half + 2 : o.s2_half;      // (+ 2: see k_net32_forward)
   for (int k = 0; k < 2; ++k)
     if (p->net[k].enabled) {
       const int rc = net_forward(p, k, s, k == 1 || !p->net[1].enabled, s2_half);
@@ -526,7 +526,21 @@ static int cap_edge(hipEvent_t e, hipStream_t from, hipStream_t to) {
   return PF_OK;
 }
 
-static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_capture& c) {
+// Does pf_problem.pad_index hold exactly what pf_pad_index_of computes (the layout pinn_fem_amd builds and INTEGRATION.md
+// describes: nets in order, pf_net_pad_index + pad_off)?  Then the forward launch's update prologue computes the index
+// instead of loading it.  One synchronous copy of the table, at graph creation only.
+static bool pad_index_is_canonical(const pf_problem* p) {
+  const int n = p->n_theta_active;
+  if (n <= 0 || !p->pad_index) return false;
+  int* h = new int[n];
+  const bool ok = hipMemcpy(h, p->pad_index, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+  bool same = ok;
+  for (int q = 0; same && q < n; ++q) same = h[q] == pf_pad_index_of(*p, q);
+  delete[] h;
+  return same;
+}
+
+static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_capture& c, bool calc_index = false) {
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
   hipStream_t s = c.s;
   // PF_GRAPH_SERIAL=1: experiment knob, the plain chain of launches inside the graph (no branches)
@@ -601,6 +615,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     if (fuse_gu && i > 0) k_prev = ((i - 1) & 1) ? c_elem_k + (size_t)q.mesh.n_elems * (q.mesh.dim == 2 ? 3 : 1) : c_elem_k;
     pf_fwd2_opts fo;
     if (fuse_s2 && i > 0) fo.s2_half = (i - 1) & 1;
+    fo.calc_index = calc_index;
     if (k_prev) {
       fo.gu_nb = pf_node_blocks(q.mesh.n_nodes);
       fo.gu_k = k_prev;
@@ -701,8 +716,10 @@ int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void
   int rc = check_gd(p);
   if (rc) return rc;
   if (!graph_out || iters_per_graph < 1) return fail(PF_ERR_ARG, "pf_graph_create: bad argument");
+  static const int ci_knob = getenv("PF_CALC_INDEX") ? atoi(getenv("PF_CALC_INDEX")) : 1;   // 0: experiment knob (index table)
+  const bool calc_index = ci_knob != 0 && can_fuse_theta_update(p) && pad_index_is_canonical(p);
   return capture_graph((hipStream_t)stream, PF_CAP_EV * iters_per_graph, hipStreamCaptureModeThreadLocal, graph_out,
-                       [&](pf_capture& cap) { return enqueue_graph_iterations(p, iters_per_graph, cap); });
+                       [&](pf_capture& cap) { return enqueue_graph_iterations(p, iters_per_graph, cap, calc_index); });
 }
 
 int pf_graph_launch(void* graph, void* stream) {

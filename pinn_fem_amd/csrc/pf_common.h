@@ -119,13 +119,38 @@ __device__ __forceinline__ float* pf_theta_half_ptr(const pf_problem& P, int hal
   return P.theta_alt + (size_t)which * P.n_theta;
 }
 
+// Padded-image index of active parameter q (what pf_problem.pad_index[q] holds: pf_net_pad_index of the parameter's net +
+// the net's pad_off), by arithmetic: the forward launch's update prologue is a chain of dependent global round trips with
+// an idle vector ALU, and this replaces the first of them (index table -> row addresses) in every block of the launch.
+// Active parameters are laid out net by net, young before area.
+__host__ __device__ __forceinline__ int pf_pad_index_of(const pf_problem& P, int q) {
+  const int k = (P.net[1].enabled && (!P.net[0].enabled || q >= P.net[1].theta_off)) ? 1 : 0;
+  const int W = P.net[k].width, IN = P.net[k].in_dim, L = P.net[k].n_hidden;
+  const int hp = ((W + 3) / 4) * 4;
+  int r = q - P.net[k].theta_off;
+  const int off = P.net[k].pad_off;
+  if (r < W * IN) return off + (r / IN) * 4 + (r % IN);        // W1 (width, in_dim)
+  r -= W * IN;
+  if (r < W) return off + r * 4 + IN;                          // b1
+  r -= W;
+  for (int l = 2; l <= L; ++l) {
+    if (r < W * W) return off + pf_pad_wh(hp, l) + (r / W) * (hp + 4) + (r % W);
+    r -= W * W;
+    if (r < W) return off + pf_pad_wh(hp, l) + r * (hp + 4) + hp;
+    r -= W;
+  }
+  if (r < W) return off + pf_pad_wo(hp, L) + r;                // output weights, then the output bias
+  return off + pf_pad_wo(hp, L) + hp;
+}
+
 // Parameter update (one block, thread q -> parameter q): PF_RG second-level partial rows -> grad_theta[q], then
 // optimizer_theta.step() (solver.py:293-294).  new_theta (LDS, n_theta_active floats) receives the updated parameters
 // when non-null.  The state is read from half `half_in` and stored to half `half_out` (0, 0: in place).
 // skip_stores: compute only (the block-uniform stop flag as loaded by the caller — the loads below are then issued WITH
 // that load instead of behind a branch on it; or a block of the forward launch that only needs its own copy).
+// calc_index: the padded-image index by arithmetic (pf_pad_index_of) instead of from the table.
 __device__ __forceinline__ void pf_theta_update(const pf_problem& P, int fuse_adam, float* new_theta, int skip_stores = 0,
-                                                int half_in = 0, int half_out = 0) {
+                                                int half_in = 0, int half_out = 0, bool calc_index = false) {
   PF_NO_CONTRACT
   const float* __restrict__ p2 = P.partials + PF_PART_WG + (size_t)P.n_part_blocks * P.pad_total;
   const float step_size = P.state->step_size_t, bc2s = P.state->bc2_sqrt;
@@ -138,7 +163,7 @@ __device__ __forceinline__ void pf_theta_update(const pf_problem& P, int fuse_ad
   float* m_o = pf_theta_half_ptr(P, half_out, 1);
   float* v_o = pf_theta_half_ptr(P, half_out, 2);
   for (int q = threadIdx.x; q < P.n_theta_active; q += blockDim.x) {
-    const int pi = P.pad_index[q];
+    const int pi = calc_index ? pf_pad_index_of(P, q) : P.pad_index[q];
     float th = th_i[q];
     float m = 0.f, v = 0.f;
     if (fuse_adam) { m = m_i[q]; v = v_i[q]; }
@@ -373,10 +398,13 @@ PF_DECL_NET_LAUNCHERS(32)
 
 // What a fused forward launch (pf_net32.hip: k_net32_forward2) does besides the two forward passes (the iteration graph):
 //   s2_half >= 0  the parameter update of the previous iteration from that state half (fwd_theta_prologue)
+//   calc_index    ... with the padded-image index of a parameter by arithmetic (pf_pad_index_of; the caller has checked
+//                 that pf_problem.pad_index holds exactly that) instead of from the table
 //   gu_nb > 0     the displacement update of the previous iteration (pf_node.h) reading the stiffness records gu_k; gu_nb =
 //                 entries of the u-norm partial sums the bookkeeping reads
 struct pf_fwd2_opts {
   int s2_half = -1;
+  bool calc_index = false;
   int gu_nb = 0;
   const float* gu_k = nullptr;
 };

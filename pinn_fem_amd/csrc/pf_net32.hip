@@ -810,14 +810,15 @@ __device__ __forceinline__ void stage1_group(const pf_problem& P, int nb_rows, i
 // also stores the new state into the other half, the images (with the backward's scaling bound) and the theta-norm
 // monitor to global memory and flips state->theta_half: nothing any block of this launch reads.  Two block barriers.
 __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half_in, unsigned char* img_lds0,
-                                                   unsigned char* img_lds1, float* new_theta, int img_bytes, int* s_done) {
+                                                   unsigned char* img_lds1, float* new_theta, int img_bytes, int* s_done,
+                                                   bool calc_index = false) {
   const bool lead = blockIdx.x == 0;
   // The stop flag is stable while a forward launch runs (the bookkeeping that raises it is ordered behind it), so the lead
   // block may read it for itself, and every block's update loads leave together with the block's one flag read instead
   // of behind a barrier on it.
   const int done0 = lead ? P.state->done : 1;
   if (threadIdx.x == 0) *s_done = P.state->done;
-  pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1);
+  pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1, calc_index);
   __syncthreads();
   if (*s_done) return;
   // (two nets: the two halves of the block pack them side by side)
@@ -863,6 +864,8 @@ constexpr int FW_THREADS = 1024;
 template <int NR, int L, int IN>
 __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg_arg, int ws, int s2_half) {
   using E = Eng<NR>;
+  const bool calc_index = s2_half >= 2;       // (s2_half + 2: padded-image indices by arithmetic, pf_fwd2_opts.calc_index)
+  if (calc_index) s2_half -= 2;
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
   extern __shared__ __align__(16) unsigned char smem[];
   const pf_net net = P.net[which];
@@ -895,7 +898,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int 
   __shared__ int s_done;
   if (s2_half >= 0) {
     fwd_theta_prologue(P, s2_half, which == 0 ? smem : nullptr, which == 1 ? smem : nullptr,
-                       reinterpret_cast<float*>(smem + ((pf_n32_bytes(L) + 255) & ~255)), pf_n32_bytes(L), &s_done);
+                       reinterpret_cast<float*>(smem + ((pf_n32_bytes(L) + 255) & ~255)), pf_n32_bytes(L), &s_done, calc_index);
   } else {
     if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
@@ -969,6 +972,8 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
                                                                const float* __restrict__ gu_k) {
   using EE = Eng<NRE>;
   using EA = Eng<NRA>;
+  const bool calc_index = s2_half >= 2;       // (s2_half + 2: padded-image indices by arithmetic, pf_fwd2_opts.calc_index)
+  if (calc_index) s2_half -= 2;
   const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int IMG = pf_n32_bytes(L), IMGP = (IMG + 255) & ~255;
@@ -1035,7 +1040,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
     return true;
   };
   if (s2_half >= 0) {
-    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done);
+    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done, calc_index);
   } else {
     if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
@@ -1462,7 +1467,7 @@ int launch_fwd2_t(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o) {
   static const int queue_knob = getenv("PF_FWD_QUEUE") ? atoi(getenv("PF_FWD_QUEUE")) : 1;
   const int queue = gu_nb > 0 ? 1 : queue_knob;       // (the displacement update rides on the queue form only)
   if (gu_nb > 0 && !pf_n32_fwd2_can_update_u(p, gu_nb)) { pf_set_error("fused forward: displacement update not possible on this problem"); return PF_ERR_UNSUPPORTED; }
-  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half, queue, gu_nb, o.gu_k);
+  hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half >= 0 && o.calc_index ? s2_half + 2 : s2_half, queue, gu_nb, o.gu_k);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>

@@ -1040,6 +1040,50 @@ def test_graph_equals_eager_meshes(mesh, n, fe):
     assert np.all(np.isfinite(outs[0][-1]))
 
 
+@pytest.mark.parametrize("layers,we,wa,dim", [(1, 7, 4, 2), (3, 8, 12, 2), (2, 27, 30, 2), (3, 30, 5, 1), (1, 16, 16, 1)])
+def test_graph_equals_eager_net_shapes(layers, we, wa, dim):
+    """The update prologue of the graph's forward launches computes the padded-image index of every parameter by arithmetic
+    (pf_pad_index_of) where the eager update reads pf_problem.pad_index: same bits in theta, the Adam moments and u for one,
+    two and three hidden layers, ragged widths (register buckets 4 ... 15) and both input dimensions."""
+    from pinn_fem_amd.engine import HipEngine
+    from pinn_fem_amd.fem.model import FEMModel, Material
+    from pinn_fem_amd.fem.properties import NNProperty
+    from pinn_fem_amd.fem.solver import SolverConfig
+    from pinn_fem_amd.nets import SimpleNN
+    n = 5000
+    outs = []
+    for use_graph in (True, False):
+        rng = np.random.default_rng(7)
+        torch.manual_seed(9)
+        if dim == 2:
+            nodes = np.stack([np.arange(n + 1) * (3.0 / n), np.zeros(n + 1)], 1)
+            fixed = np.array([0, 1])
+        else:
+            nodes = np.arange(n + 1) * (3.0 / n)
+            fixed = np.array([0])
+        elements = np.stack([np.arange(n), np.arange(1, n + 1)], 1)
+        ndof = (n + 1) * dim
+        loads = rng.normal(size=ndof) * 0.1
+        md = rng.choice(np.arange(dim, ndof), size=n // 5, replace=False)
+        mv = rng.normal(size=len(md)) * 0.02
+        model = FEMModel(nodes, elements, Material(NNProperty(SimpleNN(layers, we, dim + 1), dim + 1, True, 1.5),
+                                                   NNProperty(SimpleNN(layers, wa, dim + 1), dim + 1, True, 0.7)),
+                         loads, fixed, dimension=dim)
+        cfg = SolverConfig(max_iterations=40, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
+        eng = HipEngine(model, mv, md)
+        eng.begin(None, 0.2, cfg, want_history=True)
+        n_it = 2 * eng.GRAPH_ITERS + 1
+        eng.iterate(n_it, use_graph=use_graph)
+        torch.cuda.synchronize()
+        assert eng.state().iter == n_it
+        outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.m_t.cpu().numpy().copy(),
+                     eng.v_t.cpu().numpy().copy(), eng.history(n_it).copy()))
+        del eng
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):
+        assert np.array_equal(a, b)
+    _assert_history_equal(outs[0][-1], outs[1][-1])
+
+
 @pytest.mark.parametrize("max_it,tol,expect", [(40, 1e30, 12), (13, 0.0, 13), (15, 0.0, 15)])
 def test_graph_stop_in_mid_replay_equals_eager(max_it, tol, expect):
     """The iteration graph ping-pongs the displacement vector and the parameter state between two halves; a stop raised
