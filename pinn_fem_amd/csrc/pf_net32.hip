@@ -308,8 +308,12 @@ struct Eng {
 
   // tanh of the NR pre-activations z[r] * cz of BOTH tiles; writes the packed pairs (and t, aL) of layer LL
   template <int L, bool BWD, int LL>
+  // go (backward pass, last hidden layer): the output unit's weight-gradient row takes g0 a'_L (tile 0), then g1 a'_L (tile
+  // 1) right here, where a'_L is formed — kept for the back-propagation's start it had to be rebuilt from r at the end of
+  // every task (twenty fma) and held twenty registers over both tiles' back-propagation.
   static __device__ __forceinline__ void activate2(TileAct<L, BWD>& A0, TileAct<L, BWD>& A1, const float (&z0)[NR],
-                                            const float (&z1)[NR], float cz, int dbg = 0) {
+                                            const float (&z1)[NR], float cz, int dbg = 0, float* go = nullptr,
+                                            float g0 = 0.f, float g1 = 0.f) {
     float e0[NR], e1[NR];
     PF_STAGE();
     if (dbg & 4) {   // timing experiment: no transcendentals
@@ -337,7 +341,10 @@ struct Eng {
         A0.t[LL - 1][R] = fmaf(-e0[R], e0[R], e0[R]);
         A1.t[LL - 1][R] = fmaf(-e1[R], e1[R], e1[R]);
       }
-      if constexpr (LL == L) { A0.aL[R] = a0[R]; A1.aL[R] = a1[R]; }
+      if constexpr (LL == L) {
+        if (BWD && go) { go[R] = fmaf(g0, a0[R], go[R]); go[R] = fmaf(g1, a1[R], go[R]); }
+        else { A0.aL[R] = a0[R]; A1.aL[R] = a1[R]; }
+      }
     });
     if constexpr (NR & 1) { a0[NR] = 0.f; a1[NR] = 0.f; }
     sfor<0, NPK>([&](auto q) {
@@ -357,7 +364,8 @@ struct Eng {
   // products: the stages of the two tiles are staggered by one, every stage still holds ~2 NR independent instructions.
   template <int L, bool BWD, int LL>
   static __device__ __forceinline__ void activate2_staggered(TileAct<L, BWD>& A0, TileAct<L, BWD>& A1, float (&e0)[NR],
-                                                             const float (&z1)[NR], float cz) {
+                                                             const float (&z1)[NR], float cz, float* go = nullptr,
+                                                             float g0 = 0.f, float g1 = 0.f) {
     float e1[NR];
     sfor<0, NR>([&](auto r) {
       constexpr int R = r;
@@ -371,7 +379,10 @@ struct Eng {
       e1[R] = __builtin_amdgcn_rcpf(e1[R] + 1.0f);
       a0[R] = fmaf(-2.0f * PF_N32_KA, e0[R], PF_N32_KA);
       if constexpr (BWD) A0.t[LL - 1][R] = fmaf(-e0[R], e0[R], e0[R]);
-      if constexpr (LL == L) A0.aL[R] = a0[R];
+      if constexpr (LL == L) {
+        if (BWD && go) go[R] = fmaf(g0, a0[R], go[R]);
+        else A0.aL[R] = a0[R];
+      }
     });
     if constexpr (NR & 1) { a0[NR] = 0.f; a1[NR] = 0.f; }
     PF_STAGE();
@@ -379,7 +390,10 @@ struct Eng {
       constexpr int R = r;
       a1[R] = fmaf(-2.0f * PF_N32_KA, e1[R], PF_N32_KA);
       if constexpr (BWD) A1.t[LL - 1][R] = fmaf(-e1[R], e1[R], e1[R]);
-      if constexpr (LL == L) A1.aL[R] = a1[R];
+      if constexpr (LL == L) {
+        if (BWD && go) go[R] = fmaf(g1, a1[R], go[R]);
+        else A1.aL[R] = a1[R];
+      }
     });
     sfor<0, NPK>([&](auto q) {
       constexpr int Q = q;
@@ -430,7 +444,8 @@ struct Eng {
   template <int L, int IN, bool BWD>
   static __device__ __forceinline__ void forward_tiles(const unsigned char* __restrict__ img, int lane, const float (&x0)[3],
                                                 const float (&x1)[3], TileAct<L, BWD>& A0, TileAct<L, BWD>& A1,
-                                                float& p0, float& p1, int dbg = 0, int grp = -1) {
+                                                float& p0, float& p1, int dbg = 0, int grp = -1, float* go = nullptr,
+                                                float g0 = 0.f, float g1 = 0.f) {
     const int h = lane >> 5;
     constexpr float C2 = 2.8853900817779268f;   // 2 log2(e)
     LayerW wl[L > 1 ? L - 1 : 1];
@@ -447,7 +462,7 @@ struct Eng {
         z0[R] = layer1_row<IN>(w1v[R], x0);
         z1[R] = layer1_row<IN>(w1v[R], x1);
       });
-      activate2<L, BWD, 1>(A0, A1, z0, z1, C2, dbg);
+      activate2<L, BWD, 1>(A0, A1, z0, z1, C2, dbg, go, g0, g1);
     }
     if (grp == 1) __builtin_amdgcn_s_barrier();      // lockstep point of wave group 1 (see k_net32_forward)
     // hidden layers 2..L on the matrix cores: z' = KA KW z, bias as the initial accumulator
@@ -488,7 +503,7 @@ struct Eng {
         });
         float z1[NR];
         sfor<0, NR>([&](auto r) { constexpr int R = r; z1[R] = acc1[R]; });
-        activate2_staggered<L, BWD, LL>(A0, A1, e0, z1, CZ);
+        activate2_staggered<L, BWD, LL>(A0, A1, e0, z1, CZ, go, g0, g1);
       } else {
       if (!(dbg & 8)) {
         sfor<0, KS>([&](auto s) {
@@ -509,17 +524,19 @@ struct Eng {
       else load_wo(img, lane, wv);
       float z0[NR], z1[NR];
       sfor<0, NR>([&](auto r) { constexpr int R = r; z0[R] = acc0[R]; z1[R] = acc1[R]; });
-      activate2<L, BWD, LL>(A0, A1, z0, z1, CZ, dbg);
+      activate2<L, BWD, LL>(A0, A1, z0, z1, CZ, dbg, go, g0, g1);
       }
     });
     if (grp == 2) __builtin_amdgcn_s_barrier();
     p0 = 0.f;
     p1 = 0.f;
-    sfor<0, NR>([&](auto r) {
-      constexpr int R = r;
-      p0 = fmaf(wv[R], A0.aL[R], p0);
-      p1 = fmaf(wv[R], A1.aL[R], p1);
-    });
+    if constexpr (!BWD) {      // (the backward pass takes the output from the forward launch's stored value)
+      sfor<0, NR>([&](auto r) {
+        constexpr int R = r;
+        p0 = fmaf(wv[R], A0.aL[R], p0);
+        p1 = fmaf(wv[R], A1.aL[R], p1);
+      });
+    }
   }
 
   // tanh of the NR pre-activations of ONE tile (backward recompute): same stages as activate2
@@ -1260,30 +1277,30 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
       }
     }
     // ---- the two tiles ------------------------------------------------------------------------------------------
-    auto tile_backward = [&](const typename E::template TileAct<L, true>& A, const float (&xt)[3], float gt) {
+    auto tile_backward = [&](const typename E::template TileAct<L, true>& A, const float (&xt)[3], float gt, bool go_done) {
       // inputs of the combined tile: (kl lam, kx x, kx y, 1) resp. (kl lam, kx x, 1, 0)
       unsigned xhi[NPK], xlo[NPK];
       sfor<2, NPK>([&](auto q) { constexpr int Q = q; xhi[Q] = 0u; xlo[Q] = 0u; });
       split_pair(kl * xt[0], kx * xt[1], xhi[0], xlo[0]);
       split_pair(IN == 3 ? kx * xt[2] : 1.0f, IN == 3 ? 1.0f : 0.f, xhi[1], xlo[1]);
       // (before backward_tile: a'_L is dead there, ten registers less at the kernel's pressure peak)
-      sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = fmaf(gt, A.aL[R], go[R]); });
+      if (!go_done) sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = fmaf(gt, A.aL[R], go[R]); });
       if (!(dbg & 2)) E::template backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, wb, rd, dbg);
     };
     if constexpr (E::template bw_pair<L>()) {   // recompute both tiles together, then the two back-propagations (see bw_pair)
       const float x0[3] = {lam_in, xa0, xb0}, x1[3] = {lam_in, xa1, xb1};
       typename E::template TileAct<L, true> A0, A1;
       float p0, p1;
-      E::template forward_tiles<L, IN, true>(smem, lane, x0, x1, A0, A1, p0, p1);
-      tile_backward(A0, x0, g0);
-      tile_backward(A1, x1, g1);
+      E::template forward_tiles<L, IN, true>(smem, lane, x0, x1, A0, A1, p0, p1, 0, -1, go, g0, g1);
+      tile_backward(A0, x0, g0, true);
+      tile_backward(A1, x1, g1, true);
     } else {
       sfor<0, 2>([&](auto tt) {
         constexpr int TT = tt;
         const float xt[3] = {lam_in, TT ? xa1 : xa0, TT ? xb1 : xb0};
         typename E::template TileAct<L, true> A;
         E::template recompute_tile<L, IN>(smem, lane, xt, A);
-        tile_backward(A, xt, TT ? g1 : g0);
+        tile_backward(A, xt, TT ? g1 : g0, false);
       });
     }
     gbo += gz;
