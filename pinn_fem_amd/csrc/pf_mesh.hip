@@ -106,27 +106,64 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
   const int fp = fin_prev ? 1 : 0;     // (fin_prev is 1 or 2: ONE extra block either way)
   const int bid = (int)blockIdx.x - fp, nblk = (int)gridDim.x - fp;
   float sum_r2 = 0.f, sum_d2 = 0.f;
-  for (int node = bid * blockDim.x + threadIdx.x; node < M.n_nodes; node += nblk * blockDim.x) {
-    float f[2];
-    gather_kv<DIM>(P, P.u, node, f);
+  // one node: residual, dL/df_int, the two loss sums (f = this node's internal force)
+  auto finish = [&](int node, const float* f, const unsigned* fl, const float* fx, const float* un, const float* mv) {
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
       const int dof = node * DIM + c;
-      const unsigned fl = M.dof_flags[dof];
-      const bool mine = !(fl & PF_DOF_GHOST);
+      const bool mine = !(fl[c] & PF_DOF_GHOST);
       if (f_int_out) f_int_out[dof] = f[c];
       if (!compute_loss) continue;
       float gf = 0.f;
-      if (!(fl & PF_DOF_FIXED)) {
-        const float r = f[c] - P.lam * M.f_ext[dof];  // solver.py:267-269
+      if (!(fl[c] & PF_DOF_FIXED)) {
+        const float r = f[c] - P.lam * fx[c];           // solver.py:267-269
         if (mine) sum_r2 += r * r;
-        gf = P.alpha_physics * r;                     // d(alpha_p * 0.5*sum r^2)/dr
+        gf = P.alpha_physics * r;                       // d(alpha_p * 0.5*sum r^2)/dr
       }
       P.g_f[dof] = gf;
-      if (mine && P.use_data && (fl & PF_DOF_MEASURED)) {
-        const float d = M.meas_val[dof] - P.u[dof];   // solver.py:274
+      if (mine && P.use_data && (fl[c] & PF_DOF_MEASURED)) {
+        const float d = mv[c] - un[c];                  // solver.py:274
         sum_d2 += d * d;
       }
+    }
+  };
+  const int stride = nblk * (int)blockDim.x;
+  int node = bid * (int)blockDim.x + (int)threadIdx.x;
+  if (P.elem_k && P.adj_other && !f_int_out) {
+    // Two nodes of the thread's grid-stride walk at a time, every level of both gathers in flight together
+    // (gather_kv_multi, pf_node.h): three dependent round trips per pair instead of six.  Same per-node arithmetic and the
+    // same order of the thread's loss sums (first node, then second) as the one-by-one walk below.
+    const float* __restrict__ mvals = P.use_data ? M.meas_val : P.u;
+    for (; node < M.n_nodes; node += 2 * stride) {
+      const bool two = node + stride < M.n_nodes;
+      const int nd[2] = {node, two ? node + stride : node};
+      unsigned fl[2][2];
+      float fx[2][2], un[2][2], mv[2][2], f[2][2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        load_vec<DIM>(M.f_ext, nd[m], fx[m]);
+        load_vec<DIM>(P.u, nd[m], un[m]);
+        load_vec<DIM>(mvals, nd[m], mv[m]);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) fl[m][c] = M.dof_flags[nd[m] * DIM + c];
+      }
+      gather_kv_multi<DIM, 2>(P, P.elem_k, P.u, nd, f);
+      finish(nd[0], f[0], fl[0], fx[0], un[0], mv[0]);
+      if (two) finish(nd[1], f[1], fl[1], fx[1], un[1], mv[1]);
+    }
+  } else {
+    for (; node < M.n_nodes; node += stride) {
+      float f[2], fx[2] = {0.f, 0.f}, un[2] = {0.f, 0.f}, mv[2] = {0.f, 0.f};
+      unsigned fl[2] = {0u, 0u};
+      gather_kv<DIM>(P, P.u, node, f);
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        const int dof = node * DIM + c;
+        fl[c] = M.dof_flags[dof];
+        fx[c] = M.f_ext[dof];
+        if (P.use_data && (fl[c] & PF_DOF_MEASURED)) { mv[c] = M.meas_val[dof]; un[c] = P.u[dof]; }
+      }
+      finish(node, f, fl, fx, un, mv);
     }
   }
   if (!compute_loss) return;

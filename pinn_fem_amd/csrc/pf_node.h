@@ -198,3 +198,68 @@ __device__ __forceinline__ float node_gradu_task(const NodeView& P, const float*
   }
   return sum_u2;
 }
+
+// ---- the same gather for M nodes per THREAD (node kernels): (K(theta) v)[node] over the incident elements of each node,
+// every level's loads of all M nodes issued before the first wait.  The stand-alone node kernels walk two nodes per
+// thread one after the other (grid-stride): six dependent round trips per thread; taken together they are three.
+// Same accumulation order per node as gather_kv (pf_mesh.hip), same ke_rows_times: same bits.  Needs adj_other and the
+// stiffness records.
+template <int DIM, int M>
+__device__ __forceinline__ void gather_kv_multi(const pf_problem& P, const float* __restrict__ elem_k,
+                                                const float* __restrict__ v, const int (&node)[M], float (&acc)[M][2]) {
+  const pf_mesh& Ms = P.mesh;
+  int b[M], e_[M];
+  float vs[M][2];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    b[m] = Ms.adj_ptr[node[m]];
+    e_[m] = Ms.adj_ptr[node[m] + 1];
+    load_vec<DIM>(v, node[m], vs[m]);
+    acc[m][0] = 0.f;
+    acc[m][1] = 0.f;
+  }
+  int rounds = 0;
+#pragma unroll
+  for (int m = 0; m < M; ++m) rounds = max(rounds, (e_[m] - b[m] + 1) >> 1);
+  for (int r = 0; r < rounds; ++r) {
+    int code0[M], code1[M], oth0[M], oth1[M];
+    bool has[M], two[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int idx = b[m] + 2 * r;
+      has[m] = idx < e_[m];
+      two[m] = idx + 1 < e_[m];
+      const int i0 = has[m] ? idx : 0, i1 = two[m] ? idx + 1 : i0;
+      code0[m] = Ms.adj[i0];
+      oth0[m] = P.adj_other[i0];
+      code1[m] = Ms.adj[i1];
+      oth1[m] = P.adj_other[i1];
+    }
+    ElemK k0[M], k1[M];
+    float w0[M][2], w1[M][2];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      k0[m] = load_k_record<DIM>(elem_k, code0[m] >> 1);
+      k1[m] = load_k_record<DIM>(elem_k, code1[m] >> 1);
+      load_vec<DIM>(v, oth0[m], w0[m]);
+      load_vec<DIM>(v, oth1[m], w1[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      float fe[2];
+      const int end0 = code0[m] & 1, end1 = code1[m] & 1;
+      ke_rows_times<DIM>(k0[m], end0, end0 ? w0[m] : vs[m], end0 ? vs[m] : w0[m], fe, P.fe_mode);
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        const float t = acc[m][c] + fe[c];
+        acc[m][c] = has[m] ? t : acc[m][c];
+      }
+      ke_rows_times<DIM>(k1[m], end1, end1 ? w1[m] : vs[m], end1 ? vs[m] : w1[m], fe, P.fe_mode);
+#pragma unroll
+      for (int c = 0; c < DIM; ++c) {
+        const float t = acc[m][c] + fe[c];
+        acc[m][c] = two[m] ? t : acc[m][c];
+      }
+    }
+  }
+}
