@@ -200,10 +200,8 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
   const pf_mesh& M = P.mesh;
   const GraduConsts K = gradu_consts(P);
   float sum_u2 = 0.f;
-  for (int node = blockIdx.x * blockDim.x + threadIdx.x; node < M.n_nodes;
-       node += gridDim.x * blockDim.x) {
-    float g[2];
-    gather_kv<DIM>(P, P.g_f, node, g);  // K symmetric: K^T g_f by the same gather
+  // one node: data term, gradient store, Adam step / clamp, norm of u_free (g = this node's K^T g_f entry)
+  auto finish = [&](int node, const float* g) {
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
       const int dof = node * DIM + c;
@@ -228,6 +226,26 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
         P.v_u[dof] = v;
         (u_out ? u_out : P.u)[dof] = uo;
       }
+    }
+  };
+  const int stride = (int)(gridDim.x * blockDim.x);
+  int node = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (P.elem_k && P.adj_other) {
+    // two nodes of the thread's walk at a time, both gathers level by level together (gather_kv_multi, pf_node.h; K
+    // symmetric: K^T g_f by the same gather as the residual's); same arithmetic and order as the walk below
+    for (; node < M.n_nodes; node += 2 * stride) {
+      const bool two = node + stride < M.n_nodes;
+      const int nd[2] = {node, two ? node + stride : node};
+      float g2[2][2];
+      gather_kv_multi<DIM, 2>(P, P.elem_k, P.g_f, nd, g2);
+      finish(nd[0], g2[0]);
+      if (two) finish(nd[1], g2[1]);
+    }
+  } else {
+    for (; node < M.n_nodes; node += stride) {
+      float g[2];
+      gather_kv<DIM>(P, P.g_f, node, g);  // K symmetric: K^T g_f by the same gather
+      finish(node, g);
     }
   }
   if (FUSE_ADAM) {
@@ -767,9 +785,11 @@ __global__ __launch_bounds__(256) void k_coo_k(pf_problem P, long long* __restri
 #define PF_CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP)
 
 int pf_node_blocks(int n_nodes) {
-  // measured at 10^6 nodes (MI355X): 2048 blocks (8 waves per SIMD, ~2 nodes per thread) beat both 1024
-  // and one-node-per-thread 4096 by 2-3 us per node kernel.  PF_NODE_BLOCKS: experiment knob.
-  static const int cap = getenv("PF_NODE_BLOCKS") ? atoi(getenv("PF_NODE_BLOCKS")) : 2048;
+  // measured at 10^6 nodes (MI355X) with the pairwise walk of the node kernels (two nodes of a thread at a time):
+  // 1024 blocks (4 waves per SIMD, two pairs per thread) 0.1398 ms per iteration against 0.1412 (2048), 0.1417 (1280),
+  // 0.1419 (768), 0.1432 (512) (profiles/r03_ab.txt; the one-node-at-a-time kernels of round 2 were best at 2048).
+  // PF_NODE_BLOCKS: experiment knob.
+  static const int cap = getenv("PF_NODE_BLOCKS") ? atoi(getenv("PF_NODE_BLOCKS")) : 1024;
   int nb = (n_nodes + PF_NODE_THREADS - 1) / PF_NODE_THREADS;
   if (nb > cap) nb = cap;
   if (nb > PF_MAX_NODE_BLOCKS) nb = PF_MAX_NODE_BLOCKS;
