@@ -31,7 +31,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-I" + os.path.j
 def _sources():
     # experiment build: nodes per lane of a node task inside the fused forward launch (pf_net32.h: PF_GU_M)
     gu = ["-DPF_GU_M=" + str(int(os.environ["PINNFEM_GU_M"]))] if os.environ.get("PINNFEM_GU_M") else []
-    units = [("pf_api.o", "pf_api.hip", gu), ("pf_mesh.o", "pf_mesh.hip", ["-fno-slp-vectorize"]),
+    units = [("pf_api.o", "pf_api.hip", gu), ("pf_mesh.o", "pf_mesh.hip", ["-fno-slp-vectorize"] +
+                                                     (["-DPF_RESIDUAL_NODES=" + str(int(os.environ["PINNFEM_RESIDUAL_NODES"]))]
+                                                      if os.environ.get("PINNFEM_RESIDUAL_NODES") else [])),
              ("pf_comm.o", "pf_comm.hip", []), ("pf_pcg.o", "pf_pcg.hip", [])]
     # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (gfx950's register file is unified), which
     # removes the v_accvgpr_read copies in front of every tanh

@@ -88,6 +88,9 @@ __device__ void finalize_body(const pf_problem& P, int nb_node, int mode, int wi
 // fin_prev (1, or 2 = with tn_ready): block 0 does the bookkeeping of the PREVIOUS iteration (finalize_body: monitors, history row, stop test,
 // next Adam scalars) from the other half of the residual sums while the remaining blocks work on this iteration's
 // nodes — the single-block, latency-bound finalize then costs nothing and needs no branch of its own in the graph.
+#ifndef PF_RESIDUAL_NODES
+#define PF_RESIDUAL_NODES 2
+#endif
 template <int DIM>
 __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72))) void k_node_residual(pf_problem P, float* f_int_out,
                                                                     int compute_loss, int fin_prev) {
@@ -130,26 +133,30 @@ __global__ __launch_bounds__(PF_NODE_THREADS) __attribute__((amdgpu_num_sgpr(72)
   const int stride = nblk * (int)blockDim.x;
   int node = bid * (int)blockDim.x + (int)threadIdx.x;
   if (P.elem_k && P.adj_other && !f_int_out) {
-    // Two nodes of the thread's grid-stride walk at a time, every level of both gathers in flight together
-    // (gather_kv_multi, pf_node.h): three dependent round trips per pair instead of six.  Same per-node arithmetic and the
-    // same order of the thread's loss sums (first node, then second) as the one-by-one walk below.
+    // PF_RESIDUAL_NODES nodes of the thread's grid-stride walk at a time, every level of their gathers in flight together
+    // (gather_kv_multi, pf_node.h): three dependent round trips per group instead of three per node.  Same per-node
+    // arithmetic and the same order of the thread's loss sums (the nodes in walk order) as the one-by-one walk below.
     const float* __restrict__ mvals = P.use_data ? M.meas_val : P.u;
-    for (; node < M.n_nodes; node += 2 * stride) {
-      const bool two = node + stride < M.n_nodes;
-      const int nd[2] = {node, two ? node + stride : node};
-      unsigned fl[2][2];
-      float fx[2][2], un[2][2], mv[2][2], f[2][2];
+    constexpr int NW = PF_RESIDUAL_NODES;       // nodes of the walk taken together
+    for (; node < M.n_nodes; node += NW * stride) {
+      int nd[NW];
+      bool ok[NW];
+      unsigned fl[NW][2];
+      float fx[NW][2], un[NW][2], mv[NW][2], f[NW][2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < NW; ++m) {
+        ok[m] = node + m * stride < M.n_nodes;
+        nd[m] = ok[m] ? node + m * stride : node;
         load_vec<DIM>(M.f_ext, nd[m], fx[m]);
         load_vec<DIM>(P.u, nd[m], un[m]);
         load_vec<DIM>(mvals, nd[m], mv[m]);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) fl[m][c] = M.dof_flags[nd[m] * DIM + c];
       }
-      gather_kv_multi<DIM, 2>(P, P.elem_k, P.u, nd, f);
-      finish(nd[0], f[0], fl[0], fx[0], un[0], mv[0]);
-      if (two) finish(nd[1], f[1], fl[1], fx[1], un[1], mv[1]);
+      gather_kv_multi<DIM, NW>(P, P.elem_k, P.u, nd, f);
+#pragma unroll
+      for (int m = 0; m < NW; ++m)
+        if (ok[m]) finish(nd[m], f[m], fl[m], fx[m], un[m], mv[m]);
     }
   } else {
     for (; node < M.n_nodes; node += stride) {
