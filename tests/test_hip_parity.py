@@ -995,13 +995,15 @@ def test_full_size_graph_equals_eager_bitwise():
 
 
 @pytest.mark.parametrize("mesh,n,fe", [("chain", 3000, 0), ("chain", 60_000, 1), ("warren", 60_000, 0), ("warren", 250_000, 1),
-                                       ("bar1d", 70_001, 0), ("bar1d", 70_001, 1)])
+                                       ("bar1d", 70_001, 0), ("bar1d", 70_001, 1), ("truss", 2500, 0)])
 def test_graph_equals_eager_meshes(mesh, n, fe):
     """The iteration graph runs the displacement update of iteration t-1 as node tasks INSIDE the forward launch of t
     (pf_node.h: 2 x 64 nodes per task, the gather rewritten with all loads of a level in flight); the eager launches use
     k_node_gradu.  Same bits in u, theta, the Adam moments and every history column but the u-norm, on: a chain with 3
     forward blocks, the Warren girder (node degree 4: two gather rounds per node), a 1-D bar (one dof per node, 4-byte
-    stiffness records, net input [load_factor, x]), element forces in the reference and in the difference form."""
+    stiffness records, net input [load_factor, x]), a random truss with shuffled, randomly oriented elements and a hub node
+    of degree 300 (150 gather rounds in one lane of a node task), element forces in the reference and in the difference
+    form."""
     from bench import build_model
     from pinn_fem_amd.engine import HipEngine
     from pinn_fem_amd.fem.model import FEMModel, Material
@@ -1021,6 +1023,16 @@ def test_graph_equals_eager_meshes(mesh, n, fe):
             model = FEMModel(nodes, elements, Material(NNProperty(SimpleNN(2, 20, 2), 2, True, 1.5),
                                                        NNProperty(SimpleNN(2, 15, 2), 2, True, 0.7)),
                              loads, np.array([0]), dimension=1)
+        elif mesh == "truss":
+            rng = np.random.default_rng(n)
+            torch.manual_seed(5)
+            nodes, elements = _random_truss(n, rng, 300)
+            loads = rng.normal(size=2 * n) * 0.05
+            fixed = np.unique(rng.choice(2 * n, size=n // 10, replace=False))
+            md = rng.choice(2 * n, size=2 * n // 3, replace=False)
+            mv = rng.normal(size=md.size) * 0.01
+            model = FEMModel(nodes, elements, Material(NNProperty(SimpleNN(2, 20, 3), 3, True, 2.0),
+                                                       NNProperty(SimpleNN(2, 15, 3), 3, True, 0.3)), loads, fixed)
         else:
             model, mv, md, _ = build_model(n, "ex4", mesh=mesh)
         cfg = SolverConfig(max_iterations=60, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4)
