@@ -828,7 +828,7 @@ __device__ __forceinline__ void stage1_group(const pf_problem& P, int nb_rows, i
 // monitor to global memory and flips state->theta_half: nothing any block of this launch reads.  Two block barriers.
 __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half_in, unsigned char* img_lds0,
                                                    unsigned char* img_lds1, float* new_theta, int img_bytes, int* s_done,
-                                                   bool calc_index = false) {
+                                                   bool calc_index = false, unsigned long long* stamps = nullptr) {
   const bool lead = blockIdx.x == 0;
   // The stop flag is stable while a forward launch runs (the bookkeeping that raises it is ordered behind it), so the lead
   // block may read it for itself, and every block's update loads leave together with the block's one flag read instead
@@ -836,7 +836,9 @@ __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half
   const int done0 = lead ? P.state->done : 1;
   if (threadIdx.x == 0) *s_done = P.state->done;
   pf_theta_update(P, 1, new_theta, done0, half_in, half_in ^ 1, calc_index);
+  if (PF_N32_DBG_ENABLE && stamps) stamps[1] = __builtin_amdgcn_s_memrealtime();
   __syncthreads();
+  if (PF_N32_DBG_ENABLE && stamps) stamps[2] = __builtin_amdgcn_s_memrealtime();
   if (*s_done) return;
   // (two nets: the two halves of the block pack them side by side)
   const bool two = P.net[0].enabled && P.net[1].enabled && blockDim.x >= 256;
@@ -850,6 +852,7 @@ __device__ __forceinline__ void fwd_theta_prologue(const pf_problem& P, int half
   };
   pack_net(0, img_lds0);
   pack_net(1, img_lds1);
+  if (PF_N32_DBG_ENABLE && stamps) stamps[3] = __builtin_amdgcn_s_memrealtime();
   __shared__ float tnorm[PF_MAX_TENSORS];
   if (lead) {
     // (the theta norm from the LDS copy, one wave per tensor in turn; inactive parameters come from p->theta)
@@ -1037,6 +1040,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   bool gu = nn_b > 0;
   int since = nn_b > 0 ? wv % (gu_every + 1) : 0;     // (the waves start out of phase)
   __shared__ int s_done;
+  unsigned long long* dstamps = nullptr;       // (diagnostic build, PF_N32_DBG=16: per-wave time stamps into pf_problem.u_alt)
   // one node task of the block's queue by the calling wave; false when the queue is empty
   auto node_task = [&]() {
     int k = 0;
@@ -1057,7 +1061,13 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
     return true;
   };
   if (s2_half >= 0) {
-    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done, calc_index);
+    if (PF_N32_DBG_ENABLE && (dbg & 16)) {
+      dstamps = reinterpret_cast<unsigned long long*>(P.u_alt) + (size_t)(blockIdx.x * waves + wv) * 8;
+      if (lane == 0) dstamps[0] = __builtin_amdgcn_s_memrealtime();
+    }
+    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done, calc_index,
+                       (dstamps && lane == 0) ? dstamps : nullptr);
+    if (dstamps && lane == 0) dstamps[4] = __builtin_amdgcn_s_memrealtime();
   } else {
     if (threadIdx.x == 0) s_done = P.state->done;
     __syncthreads();
@@ -1119,6 +1129,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
     if (grp == 3) __builtin_amdgcn_s_barrier();
     task = nxt;
   }
+  if (dstamps && lane == 0) dstamps[5] = __builtin_amdgcn_s_memrealtime();
   if (gu_nb > 0) {
     // the block's share of sum u_free^2, node tasks in index order (every wave's loop has ended: no return above this point
     // once the stop flag was read)

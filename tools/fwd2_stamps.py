@@ -1,0 +1,29 @@
+"""Diagnostic (PINNFEM_N32_DBG=1 build, PF_N32_DBG=16): where the fused forward launch of the iteration graph spends its
+time — per-wave s_memrealtime stamps (100 MHz) written into pf_problem.u_alt: 0 entry | 1 update loads + Adam done | 2 first
+barrier passed | 3 operand images packed | 4 prologue left | 5 task loop left."""
+import os, sys
+os.environ["PF_N32_DBG"] = "16"
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import build_model
+from pinn_fem_amd.engine import HipEngine
+from pinn_fem_amd.fem.solver import SolverConfig
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+model, mv, md, _ = build_model(n, "ex4")
+eng = HipEngine(model, mv, md)
+eng.begin(None, 0.1, SolverConfig(max_iterations=10**6, tolerance=0.0, learning_rate_u=0.01, learning_rate_theta=5e-4))
+eng.iterate(3 * eng.GRAPH_ITERS)
+torch.cuda.synchronize()
+raw = eng.u_alt.cpu().numpy().view(np.uint64)[: 256 * 16 * 8].reshape(-1, 8).astype(np.float64)
+raw = raw[raw[:, 0] > 0]
+t0 = raw[:, 0].min()
+us = (raw[:, :6] - t0) / 100.0
+names = ["entry", "update done", "barrier 1", "packed", "prologue left", "loop left"]
+for k, nm in enumerate(names):
+    c = us[:, k]
+    print(f"{nm:14s} min {c.min():7.2f}  med {np.median(c):7.2f}  max {c.max():7.2f} us")
+blk = us.reshape(-1, 16, 6) if len(us) % 16 == 0 else None
+if blk is not None:
+    print("block 0 (lead): prologue left at", blk[0, :, 4].max().round(2), "loop left at", blk[0, :, 5].max().round(2),
+          "| other blocks: prologue left med", np.median(blk[1:, :, 4].max(1)).round(2), "loop left med",
+          np.median(blk[1:, :, 5].max(1)).round(2), "max", blk[1:, :, 5].max().round(2))
