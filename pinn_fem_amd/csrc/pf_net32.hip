@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int
   const int n_ntasks = gu_nb > 0 ? (P.mesh.n_nodes + GUN - 1) / GUN : 0;
   const int npb = (n_ntasks + (int)gridDim.x - 1) / (int)gridDim.x;
   const int nt0 = (int)blockIdx.x * npb, nn_b = max(min(nt0 + npb, n_ntasks) - nt0, 0);
-  const int gu_every = nn_b > 0 ? max((t1 - t0) / nn_b, 0) : 0;
+  const int gu_every = nn_b > 0 ? max((t1 - t0) / nn_b + (int)(signed char)(queue >> 8), 0) : 0;     // (queue >> 8: experiment, PF_GU_EVERY_ADD)
   bool gu = nn_b > 0;
   int since = nn_b > 0 ? wv % (gu_every + 1) : 0;     // (the waves start out of phase)
   __shared__ int s_done;
@@ -1493,7 +1493,8 @@ int launch_fwd2_t(const pf_problem* p, hipStream_t s, const pf_fwd2_opts& o) {
   if (lds > 64000) { pf_set_error("too many trainable parameters for the fused theta update"); return PF_ERR_UNSUPPORTED; }
   // PF_FWD_QUEUE=0: experiment knob (round 2's lockstep rounds instead of the per-block task queue)
   static const int queue_knob = getenv("PF_FWD_QUEUE") ? atoi(getenv("PF_FWD_QUEUE")) : 1;
-  const int queue = gu_nb > 0 ? 1 : queue_knob;       // (the displacement update rides on the queue form only)
+  static const int every_add = getenv("PF_GU_EVERY_ADD") ? atoi(getenv("PF_GU_EVERY_ADD")) : 0;
+  const int queue = (gu_nb > 0 || queue_knob) ? (1 | ((every_add & 0xff) << 8)) : 0;       // (the displacement update rides on the queue form only)
   if (gu_nb > 0 && !pf_n32_fwd2_can_update_u(p, gu_nb)) { pf_set_error("fused forward: displacement update not possible on this problem"); return PF_ERR_UNSUPPORTED; }
   hipLaunchKernelGGL((k_net32_forward2<NRE, NRA, L, IN>), dim3(nb), dim3(FW_THREADS), lds, s, *p, dbg, s2_half >= 0 && o.calc_index ? s2_half + 2 : s2_half, queue, gu_nb, o.gu_k);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
