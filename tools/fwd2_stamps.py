@@ -27,3 +27,18 @@ if blk is not None:
     print("block 0 (lead): prologue left at", blk[0, :, 4].max().round(2), "loop left at", blk[0, :, 5].max().round(2),
           "| other blocks: prologue left med", np.median(blk[1:, :, 4].max(1)).round(2), "loop left med",
           np.median(blk[1:, :, 5].max(1)).round(2), "max", blk[1:, :, 5].max().round(2))
+
+# the fused backward launch (same build / knob): stamps behind the forward's, 8 per wave
+rawb = eng.u_alt.cpu().numpy().view(np.uint64)[65536: 65536 + 256 * 8 * 8].reshape(-1, 8).astype(np.float64)
+rawb = rawb[rawb[:, 0] > 0]
+if len(rawb):
+    tb = rawb[:, 0].min()
+    usb = (rawb[:, :7] - tb) / 100.0
+    for k, nm in enumerate(["bwd entry", "E loop in", "E loop out", "E row out", "A loop in", "A loop out", "A row out"]):
+        c = usb[:, k]
+        print(f"{nm:14s} min {c.min():7.2f}  med {np.median(c):7.2f}  max {c.max():7.2f} us")
+    blkb = usb.reshape(-1, 8, 7) if len(usb) % 8 == 0 else None
+    if blkb is not None:
+        endb = blkb[:, :, 6].max(1)
+        print("blocks end: min", endb.min().round(2), "med", np.median(endb).round(2), "max", endb.max().round(2),
+              "| first 160 blocks med", np.median(endb[:160]).round(2), "| last 90 blocks med", np.median(endb[-90:]).round(2))
