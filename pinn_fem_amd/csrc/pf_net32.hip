@@ -1339,495 +1339,6 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
     gbo += gz;
   }
   if (PF_N32_DBG_ENABLE && stamps) stamps[1] = __builtin_amdgcn_s_memrealtime();
-  __syncthreads();
-  if (PF_N32_DBG_ENABLE && stamps) stamps[2] = __builtin_amdgcn_s_memrealtime();
-  if (*s_done) return;
-  // (two nets: the two halves of the block pack them side by side)
-  const bool two = P.net[0].enabled && P.net[1].enabled && blockDim.x >= 256;
-  const int half = two ? ((int)blockDim.x / 2) & ~63 : 0;
-  auto pack_net = [&](int k, unsigned char* lds_img) {
-    if (!P.net[k].enabled) return;
-    unsigned char* gimg = reinterpret_cast<unsigned char*>(P.net_op + P.op_off[k]);
-    const int t_first = two ? k * half : 0, t_count = two ? (k == 0 ? half : (int)blockDim.x - half) : 0;
-    if (lds_img) pf_n32_pack(P.net[k], new_theta + P.net[k].theta_off, lds_img, P.mlp_dtype, lead, t_first, t_count);
-    else if (lead) pf_n32_pack(P.net[k], new_theta + P.net[k].theta_off, gimg, P.mlp_dtype, true, t_first, t_count);
-  };
-  pack_net(0, img_lds0);
-  pack_net(1, img_lds1);
-  if (PF_N32_DBG_ENABLE && stamps) stamps[3] = __builtin_amdgcn_s_memrealtime();
-  __shared__ float tnorm[PF_MAX_TENSORS];
-  if (lead) {
-    // (the theta norm from the LDS copy, one wave per tensor in turn; inactive parameters come from p->theta)
-    tensor_norms(P, new_theta, threadIdx.x >> 6, blockDim.x >> 6, tnorm);
-  }
-  __syncthreads();
-  if (lead) {
-    if (P.net[0].enabled && img_lds0) copy_image(reinterpret_cast<unsigned char*>(P.net_op + P.op_off[0]), img_lds0, img_bytes);
-    if (P.net[1].enabled && img_lds1) copy_image(reinterpret_cast<unsigned char*>(P.net_op + P.op_off[1]), img_lds1, img_bytes);
-    if (threadIdx.x == 0) {
-      P.state->theta_norm = (float)tensor_norm_total(P, tnorm);
-      P.state->theta_half = half_in ^ 1;
-    }
-  }
-}
-
-// ---- forward kernel ----------------------------------------------------------------------------------------
-// One block of 16 waves per CU (four per SIMD); every wave walks 64-element tasks, the block in rounds of 16 tasks.
-// The SIMD arbitrates its waves by age: left alone the oldest runs nearly unimpeded, the waves of a SIMD finish far
-// apart (measured: 26 ... 71 us for equal work) and the tail runs on one wave per SIMD.  ONE s_barrier per task
-// keeps the block's waves within a task of each other; the four wave groups (wave >> 2: one wave per SIMD each)
-// pass it at four different places of the task body, so the waves of a SIMD stay a quarter task out of phase
-// instead of reaching their transcendental, matrix and LDS phases together (MI355X_MICROARCH.md, two waves per
-// SIMD, item 9).  Lanes past the end work on the last element again (same inputs, same value) and do not store.
-constexpr int FW_THREADS = 1024;
-
-// s2_half >= 0: this launch first runs the parameter update of the previous iteration from that state half
-// (fwd_theta_prologue) and takes its operand image from there instead of from global memory.
-template <int NR, int L, int IN>
-__global__ __launch_bounds__(FW_THREADS) void k_net32_forward(pf_problem P, int which, int dbg_arg, int ws, int s2_half) {
-  using E = Eng<NR>;
-  const bool calc_index = s2_half >= 2;       // (s2_half + 2: padded-image indices by arithmetic, pf_fwd2_opts.calc_index)
-  if (calc_index) s2_half -= 2;
-  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;     // compile-time 0 in the product build (see PF_N32_DBG_ENABLE)
-  extern __shared__ __align__(16) unsigned char smem[];
-  const pf_net net = P.net[which];
-  if (s2_half < 0) copy_image(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[which]), pf_n32_bytes(L));
-  float* __restrict__ out = which == 0 ? P.prop_e : P.prop_a;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  const int grp = (dbg & 32) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);   // provably wave-uniform
-  const int n = P.mesh.n_elems;
-  const int ntasks = (n + 63) >> 6;
-  const int per_round = gridDim.x * waves;
-  const int rounds = (ntasks + per_round - 1) / per_round;        // block-uniform trip count: equal barrier counts
-  int task = blockIdx.x * waves + wv;
-  float xn[3];
-  // ws: this launch also writes the stiffness records from both properties: the other property and the element geometry
-  // travel with the coordinates, one round ahead (loaded where they are used they cost a global round trip per round)
-  const pf_net onet = P.net[1 - which];
-  const float* __restrict__ oprop = which == 0 ? P.prop_a : P.prop_e;
-  float on = onet.scale;
-  ElemGeo gn = ElemGeo{0.f, 0.f, 0.f, 1.f};
-  if (n > 0) {
-    const int e0 = min(task * 64 + lane, n - 1);
-    load_x<IN>(xn, P, e0);
-    if (ws) {
-      if (onet.enabled) on = oprop[e0];
-      gn = load_geo(P.mesh.egeo, e0);
-    }
-  }
-  // the stop flag, one read per block (the bookkeeping that raises it may run beside this launch: a block whose waves
-  // disagreed would part ways before the lockstep barriers below)
-  __shared__ int s_done;
-  if (s2_half >= 0) {
-    fwd_theta_prologue(P, s2_half, which == 0 ? smem : nullptr, which == 1 ? smem : nullptr,
-                       reinterpret_cast<float*>(smem + ((pf_n32_bytes(L) + 255) & ~255)), pf_n32_bytes(L), &s_done, calc_index);
-  } else {
-    if (threadIdx.x == 0) s_done = P.state->done;
-    __syncthreads();
-  }
-  if (s_done || n <= 0) return;
-  const float bo = reinterpret_cast<const float*>(smem + pf_n32_off_bo())[0];
-  unsigned long long st0 = 0, sr0 = 0;
-  if (dbg & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
-  for (int r = 0; r < rounds; ++r, task += per_round) {
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    const int e = task * 64 + lane;
-    float x0[3], x1[3];
-    sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
-    const float o = on;
-    const ElemGeo g = gn;
-    if (r + 1 < rounds) {
-      const int en = min(e + per_round * 64, n - 1);
-      load_x<IN>(xn, P, en);
-      if (ws) {
-        if (onet.enabled) on = oprop[en];
-        gn = load_geo(P.mesh.egeo, en);
-      }
-    }
-    typename E::template TileAct<L, false> A0, A1;
-    float p0, p1;
-    E::template forward_tiles<L, IN, false>(smem, lane, x0, x1, A0, A1, p0, p1, dbg, grp);
-    const float z = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo;
-    if (e < n) {
-      const float v = (net.positive ? pf_softplus(z) : z) * net.scale;
-      out[e] = v;
-      // stiffness record for the node kernels: s = (young * area) / l0, nn_assembly.py:74 (2-D), :37 (1-D), times the
-      // pattern entries (:84-94)
-      if (ws) store_k<IN - 1>(P.elem_k, e, g, (which == 0 ? v * o : o * v) / g.l0);
-    }
-    if (grp == 3) __builtin_amdgcn_s_barrier();
-  }
-  if ((dbg & 16) && lane == 0) {   // diagnostic build only: per-wave stamps into the (unused here) partial-sum workspace
-    unsigned long long* d = reinterpret_cast<unsigned long long*>(P.partials) + (size_t)(blockIdx.x * waves + wv) * 4 + (size_t)which * 65536;
-    d[0] = sr0; d[1] = __builtin_amdgcn_s_memrealtime(); d[2] = __builtin_amdgcn_s_memtime() - st0;
-    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    d[3] = ((unsigned long long)rounds << 48) | ((unsigned long long)(xcc & 0xf) << 32) | hwid;
-  }
-}
-
-// ---- fused forward of BOTH nets (young and area) --------------------------------------------------------------------
-// One launch instead of two: the wave's 64 elements go through the E net and then the A net (both operand images sit in
-// LDS), the coordinates are loaded and exchanged between the half-waves once, and the stiffness record is formed from
-// both values in registers — no second launch floor, no second prologue, no round trip of the first property through
-// memory.  Same block shape and lockstep scheme as k_net32_forward; the four wave groups pass their ONE barrier per task
-// at: task start | after the E net's first activation | after the A net's hidden layers | task end.
-// s2: this launch is also the THETA UPDATE of the previous iteration (the iteration graph): every block sums the
-// second-level partial rows, applies Adam to its own copy of theta and builds both operand images straight into its LDS
-// (all blocks compute the same bits); block 0 stores theta, the moments, the images and the theta-norm monitor — see
-// fwd2_theta_prologue.
-// gu_nb > 0 (the iteration graph, queue form only): this launch is also the DISPLACEMENT UPDATE of the previous iteration
-// (dL/du + Adam(u) + clamp: what k_node_gradu does, pf_node.h).  The block owns a contiguous run of node tasks (PF_GU_M x
-// 64 nodes each) beside its element tasks and its waves draw one of them after every `gu_every` element tasks: the node
-// tasks are three dependent round trips through memory with next to no arithmetic, the element tasks vector-issue bound —
-// the waves of a SIMD hide one behind the other, and the graph needs no side branch (no fork, no join: ~12 us per
-// iteration on MI355X) and no second displacement vector.  Each task's sum of u_free^2 lands in LDS at the task's index
-// and the block adds them in index order: the monitor does not depend on which wave drew what.  The block's sum goes to
-// partials[PF_PART_U2 + block]; entries up to gu_nb (what the bookkeeping sums: pf_node_blocks) are zeroed.  gu_k: the
-// stiffness records of the previous iteration (the half this launch does NOT write).
-#ifndef PF_GU_M
-#define PF_GU_M 2
-#endif
-#define PF_GU_MAX_TASKS 1024
-template <int NRE, int NRA, int L, int IN>
-__global__ __launch_bounds__(FW_THREADS) void k_net32_forward2(pf_problem P, int dbg_arg, int s2_half, int queue, int gu_nb,
-                                                               const float* __restrict__ gu_k) {
-  using EE = Eng<NRE>;
-  using EA = Eng<NRA>;
-  const bool calc_index = s2_half >= 2;       // (s2_half + 2: padded-image indices by arithmetic, pf_fwd2_opts.calc_index)
-  if (calc_index) s2_half -= 2;
-  const int dbg = PF_N32_DBG_ENABLE ? dbg_arg : 0;
-  extern __shared__ __align__(16) unsigned char smem[];
-  constexpr int IMG = pf_n32_bytes(L), IMGP = (IMG + 255) & ~255;
-  const unsigned char* __restrict__ img_e = smem;
-  const unsigned char* __restrict__ img_a = smem + IMGP;
-  const pf_net net_e = P.net[0], net_a = P.net[1];
-  if (s2_half < 0) {
-    copy_images2(smem, reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[0]), smem + IMGP,
-                 reinterpret_cast<const unsigned char*>(P.net_op + P.op_off[1]), IMG);
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  const int n = P.mesh.n_elems;
-  const int ntasks = (n + 63) >> 6;
-  // Two ways to hand the 64-element tasks to the waves.  queue (default): the block owns a contiguous run of tasks and
-  // its waves draw them from a counter in LDS, so no wave ever waits for another one — the age-ordered arbitration of a
-  // SIMD lets its oldest wave run ahead, and with a queue that wave simply takes more tasks (the waves drift out of
-  // phase by themselves).  Lockstep (queue == 0, round 2): block-uniform rounds of one task per wave with ONE s_barrier
-  // per task, passed at a different place of the task body by each of the four wave groups.
-  const int grp = (queue || (dbg & 32)) ? -1 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-  const int per_round = gridDim.x * waves;
-  const int rounds = (ntasks + per_round - 1) / per_round;
-  const int per_block = (ntasks + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t0 = (int)blockIdx.x * per_block, t1 = min(t0 + per_block, ntasks);
-  __shared__ int s_next, s_next_n;
-  __shared__ float s_u2[PF_GU_MAX_TASKS];
-  if (threadIdx.x == 0) {
-    s_next = waves;           // tasks t0 .. t0+waves-1 go to the waves in order, the rest through the queue
-    s_next_n = 0;
-  }
-  int task = queue ? t0 + wv : (int)blockIdx.x * waves + wv;
-  float xn[3];
-  ElemGeo gn = ElemGeo{0.f, 0.f, 0.f, 1.f};
-  if (n > 0) {
-    const int e0 = min(task * 64 + lane, n - 1);
-    load_x<IN>(xn, P, e0);
-    gn = load_geo(P.mesh.egeo, e0);
-  }
-  // node tasks of this block (gu_nb > 0)
-  constexpr int GUN = 64 * PF_GU_M;
-  const int n_ntasks = gu_nb > 0 ? (P.mesh.n_nodes + GUN - 1) / GUN : 0;
-  const int npb = (n_ntasks + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int nt0 = (int)blockIdx.x * npb, nn_b = max(min(nt0 + npb, n_ntasks) - nt0, 0);
-  const int gu_every = nn_b > 0 ? max((t1 - t0) / nn_b + (int)(signed char)(queue >> 8), 0) : 0;     // (queue >> 8: experiment, PF_GU_EVERY_ADD)
-  bool gu = nn_b > 0;
-  int since = nn_b > 0 ? wv % (gu_every + 1) : 0;     // (the waves start out of phase)
-  __shared__ int s_done;
-  unsigned long long* dstamps = nullptr;       // (diagnostic build, PF_N32_DBG=16: per-wave time stamps into pf_problem.u_alt)
-  // one node task of the block's queue by the calling wave; false when the queue is empty
-  auto node_task = [&]() {
-    int k = 0;
-    if (lane == 0) k = atomicAdd(&s_next_n, 1);
-    k = __builtin_amdgcn_readfirstlane(k);
-    if (k >= nn_b) return false;
-    // what the task needs of the problem is read from the kernel argument HERE (P is the first argument: offset 0 of the
-    // kernarg segment), behind an opaque move: left to the compiler, every pointer is loaded once at the top of the launch
-    // and the element loop spills scalar registers (75 against 7 without the node tasks)
-    const __attribute__((address_space(4))) pf_problem* pk =
-        (const __attribute__((address_space(4))) pf_problem*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(pk));
-    const NodeView NV = node_view_from(pk);
-    const GraduConsts GK = gradu_consts_from(pk);
-    float su = node_gradu_task<IN - 1, PF_GU_M>(NV, gu_k, GK, (nt0 + k) * GUN, lane);
-    su = pf_wave_sum(su);
-    if (lane == 0) s_u2[k] = su;
-    return true;
-  };
-  if (s2_half >= 0) {
-    if (PF_N32_DBG_ENABLE && (dbg & 16)) {
-      dstamps = reinterpret_cast<unsigned long long*>(P.u_alt) + (size_t)(blockIdx.x * waves + wv) * 8;
-      if (lane == 0) dstamps[0] = __builtin_amdgcn_s_memrealtime();
-    }
-    fwd_theta_prologue(P, s2_half, smem, smem + IMGP, reinterpret_cast<float*>(smem + 2 * IMGP), IMG, &s_done, calc_index,
-                       (dstamps && lane == 0) ? dstamps : nullptr);
-    if (dstamps && lane == 0) dstamps[4] = __builtin_amdgcn_s_memrealtime();
-  } else {
-    if (threadIdx.x == 0) s_done = P.state->done;
-    __syncthreads();
-  }
-  if (s_done || n <= 0) return;
-  const float bo_e = reinterpret_cast<const float*>(img_e + pf_n32_off_bo())[0];
-  const float bo_a = reinterpret_cast<const float*>(img_a + pf_n32_off_bo())[0];
-  for (int r = 0; queue ? (task < t1 || gu) : r < rounds; ++r) {
-    if (gu && (since >= gu_every || task >= t1)) {
-      // a node task: the next element task's inputs (already on their way) are not touched
-      since = 0;
-      gu = node_task();
-      continue;
-    }
-    if (task >= t1) break;
-    ++since;
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    // the task after this one: drawn now (queue) so that its inputs travel while this one computes
-    int nxt;
-    bool more;
-    if (queue) {
-      int k = 0;
-      if (lane == 0) k = atomicAdd(&s_next, 1);
-      nxt = t0 + __builtin_amdgcn_readfirstlane(k);
-      more = nxt < t1;
-    } else {
-      nxt = task + per_round;
-      more = r + 1 < rounds;
-    }
-    const int e = task * 64 + lane;
-    float x0[3], x1[3];
-    sfor<0, 3>([&](auto c) { constexpr int C = c; both_tiles(xn[C], x0[C], x1[C]); });
-    const ElemGeo g = gn;
-    if (more) {
-      const int en = min(nxt * 64 + lane, n - 1);
-      load_x<IN>(xn, P, en);
-      gn = load_geo(P.mesh.egeo, en);
-    }
-    float ze, za;
-    {
-      typename EE::template TileAct<L, false> A0, A1;
-      float p0, p1;
-      EE::template forward_tiles<L, IN, false>(img_e, lane, x0, x1, A0, A1, p0, p1, dbg, grp == 1 ? 1 : -1);
-      ze = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo_e;
-    }
-    {
-      typename EA::template TileAct<L, false> A0, A1;
-      float p0, p1;
-      EA::template forward_tiles<L, IN, false>(img_a, lane, x0, x1, A0, A1, p0, p1, dbg, grp == 2 ? 2 : -1);
-      za = own_total(p0, p1) * (1.0f / PF_N32_KA) + bo_a;
-    }
-    if (e < n) {
-      const float ve = (net_e.positive ? pf_softplus(ze) : ze) * net_e.scale;
-      const float va = (net_a.positive ? pf_softplus(za) : za) * net_a.scale;
-      P.prop_e[e] = ve;
-      P.prop_a[e] = va;
-      if (P.elem_k) store_k<IN - 1>(P.elem_k, e, g, (ve * va) / g.l0);    // (young * area) / l0, nn_assembly.py:74, :37
-    }
-    if (grp == 3) __builtin_amdgcn_s_barrier();
-    task = nxt;
-  }
-  if (dstamps && lane == 0) dstamps[5] = __builtin_amdgcn_s_memrealtime();
-  if (gu_nb > 0) {
-    // the block's share of sum u_free^2, node tasks in index order (every wave's loop has ended: no return above this point
-    // once the stop flag was read)
-    __syncthreads();
-    float su = 0.f;
-    for (int i = threadIdx.x; i < nn_b; i += blockDim.x) su += s_u2[i];
-    float* red = reinterpret_cast<float*>(s_u2 + PF_GU_MAX_TASKS - 16);
-    __syncthreads();
-    su = pf_block_sum(su, red);
-    if (threadIdx.x == 0) P.partials[PF_PART_U2 + blockIdx.x] = su;
-    for (int j = (int)blockIdx.x + (int)gridDim.x + (int)threadIdx.x * (int)gridDim.x; j < gu_nb; j += (int)blockDim.x * (int)gridDim.x)
-      P.partials[PF_PART_U2 + j] = 0.f;
-  }
-}
-
-// First level of the parameter-gradient reduction INSIDE the backward launch (what the k_theta_stage1 launch does
-// otherwise, to the bit: same row groups, same summation order): the block's row is complete and stored; every wave drains
-// its stores, the block takes a ticket of its row group, and the block that draws the group's last ticket sums the
-// group's rows into the group's second-level row.  No block ever waits for another one.  tickets: PF_RG counters, zero
-// between launches (the last block of a group resets its counter).
-__device__ __forceinline__ void rows_reduce_last(const pf_problem& P, int nb_rows) {
-  __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's row stores have left
-  __syncthreads();
-  const int rpg = (nb_rows + PF_RG - 1) / PF_RG;
-  const int g = (int)blockIdx.x / rpg;
-  const int r0 = g * rpg, r1 = min(r0 + rpg, nb_rows);
-  int* tickets = reinterpret_cast<int*>(P.partials + PF_PART_WG + ((size_t)P.n_part_blocks + PF_RG) * P.pad_total);
-  if (threadIdx.x == 0) {
-    const int old = __hip_atomic_fetch_add(tickets + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = old == (r1 - r0) - 1;
-    if (s_last) __hip_atomic_store(tickets + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  stage1_group(P, nb_rows, g, true, false);
-}
-
-// One net's backward over the block's tasks, as a phase of a launch: `smem` = this net's operand image in LDS (copied by
-// the caller, no barrier needed before the call), `cst` = the constant blocks (CONST_BYTES of this bucket), `wscr` = the
-// block's wave scratches (the write-out staging reuses them).  Ends with the block's partial gradient row written; the
-// caller places a block barrier between two phases that share cst / wscr.
-template <int NR, int L, int IN, bool GEA>
-__device__ __forceinline__ void backward_phase(const pf_problem& P, int which, int hp, int dbg, const unsigned char* smem,
-                                               unsigned char* cst, unsigned char* wscr, bool wt = false,
-                                               unsigned long long* stamps = nullptr) {
-  using E = Eng<NR>;
-  constexpr int CONST_BYTES = E::CONST_BYTES, WAVE_SCRATCH = E::WAVE_SCRATCH, REGION = E::REGION, NPK = E::NPK;
-  constexpr bool COMPACT = E::COMPACT;
-  typedef typename E::WriteBase WriteBase;
-  constexpr int DIM = IN - 1;
-  const pf_net net = P.net[which];
-  const pf_net onet = P.net[1 - which];
-  const float* __restrict__ other = which == 0 ? P.prop_a : P.prop_e;
-  const float* __restrict__ mine = which == 0 ? P.prop_e : P.prop_a;   // this net's forward values (pf_net_forward)
-  const int n = P.mesh.n_elems;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
-  const int h = lane >> 5;
-  unsigned char* scratch = wscr + wv * WAVE_SCRATCH;
-  for (int i = threadIdx.x; i < CONST_BYTES / 4; i += blockDim.x) reinterpret_cast<unsigned*>(cst)[i] = 0u;
-  for (int i = lane; i < WAVE_SCRATCH / 16; i += 64) reinterpret_cast<uint4*>(scratch)[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
-  // bias block: [element/4][half-wave][element%4] x (registers 12..15 as f16): KA in register 15 of the lower half-wave
-  if (threadIdx.x < 32)
-    if constexpr (COMPACT)
-      *reinterpret_cast<unsigned short*>(cst + 192 + REGION + 64 * (threadIdx.x >> 2) + 8 * (threadIdx.x & 3) + 6) = BF ? 0x4500 : 0x6800;   // 2048.0
-  const unsigned char* rd = E::operand_base(scratch, lane, cst + 192);
-  const WriteBase wb = E::write_base(scratch, lane);
-
-  const int stride = gridDim.x * waves * 64;
-  int base = (blockIdx.x * waves + wv) * 64;
-  TaskIn<DIM> nxt;
-  int2 nn_ahead = int2{0, 0};                    // node ids of the task after next (GEA only)
-  if (n > 0) {
-    task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(base + lane, n - 1));
-    if (GEA) nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(base + stride + lane, n - 1)];
-  }
-  __syncthreads();                               // (image, constant blocks and scratch are in place)
-  task_fetch_b<IN, GEA>(nxt, P);
-
-  // block-uniform scalars: keep them in SGPRs (the kernel runs at its register budget)
-  const float bound = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, reinterpret_cast<const float*>(smem)[0])));
-  const float kx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, __builtin_ldexpf(1.0f, P.coord_exp))));
-  const float inv_scale = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, 1.0f / net.scale)));
-  // scale of the load factor inside the f16 gradient products: the power of two with 2^13 <= kl |lam| < 2^14 (like the
-  // coordinates' kx; a fixed factor would overflow f16 for large |lam| and lose the lo part for small ones)
-  const float kl = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pf_n32_lam_scale(P.lam))));
-  f32x16 T[L];          // sum over this wave's tasks of S * (tile products); S = Srun, a power of two that only falls
-  sfor<0, L>([&](auto l) { constexpr int LL = l; T[LL] = zero16(); });
-  float Srun = 0.f;     // 0: not chosen yet
-  float go[NR];         // sum over own-column elements of g_z a'_L[r]
-  sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = 0.f; });
-  float gbo = 0.f;      // sum over own elements of g_z
-
-  if (PF_N32_DBG_ENABLE && stamps) stamps[0] = __builtin_amdgcn_s_memrealtime();
-  for (; base < n; base += stride) {
-    const int e = base + lane;
-    const bool live = e < n;
-    const TaskIn<DIM> cur = nxt;
-    const bool more = base + stride < n;
-    // ---- per-element scalars: one element per lane ----------------------------------------------------------
-    // softplus'(z) = sigmoid(z) = 1 - exp(-softplus(z)) from the forward's stored value (= softplus(z) * scale), so the
-    // output unit need not be recomputed (torch: z > 20 ? 1 : e^z / (e^z + 1), the same number to float round-off)
-    float gz = 0.f;
-    if (live) {
-      float gea;
-      if (GEA) {
-        gea = task_gea<DIM>(cur, P.fe_mode);
-        P.g_ea[e] = gea;
-      } else {
-        gea = cur.gea;
-      }
-      float g = gea * cur.oth;   // mul backward of young*area        (nn_assembly.py:74)
-      g = g * net.scale;         // output*scale backward              (properties.py:156)
-      gz = net.positive ? g * one_minus_exp_neg(cur.own * inv_scale) : g;
-    }
-    // power-of-two scale: max |d| S <= 2^14 with the weight bound of the image header; S only ever falls, T follows
-    // The wave-wide maximum (seven DPP steps) is only formed when it can change something: S = 2^(14 - ex) with
-    // gmax = m 2^ex, 0.5 <= m < 1, is smaller than the running S exactly when gmax * Srun >= 2^14, and a maximum passes
-    // that test iff one lane does (Srun is a power of two: the products are exact) — one multiply, one compare and a vote
-    // per task instead.
-    const float gabs = fabsf(gz) * bound;
-    if (Srun == 0.f || __builtin_amdgcn_ballot_w64(gabs * Srun >= 16384.0f) != 0ull) {
-      const float gmax = wave_max(gabs);
-      if (gmax > 0.f && gmax < 3.0e38f) {
-        int ex = 0;
-        (void)frexpf(gmax, &ex);
-        ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
-        const float Sneed = __builtin_ldexpf(1.0f, 14 - ex);
-        if (Srun == 0.f) Srun = Sneed;
-        else if (Sneed < Srun) {
-          const float f = Sneed / Srun;      // exact: powers of two
-          sfor<0, L>([&](auto l) {
-            constexpr int LL = l;
-            sfor<0, 16>([&](auto i) { constexpr int I = i; T[LL][I] *= f; });
-          });
-          Srun = Sneed;
-        }
-      }
-    }
-    const float S = Srun == 0.f ? 1.0f : Srun;
-    float g0, g1;
-    both_tiles(gz, g0, g1);
-    float xa0, xa1, xb0, xb1;
-    both_tiles(cur.x[1], xa0, xa1);
-    both_tiles(cur.x[2], xb0, xb1);
-    const float lam_in = cur.x[0];
-    if (more) {
-      // The next task's inputs leave HERE, behind the last use of this task's record (everything above consumed it: the
-      // tiles below work on derived values only), so the new values can land in the registers the old ones held — issued
-      // at the top of the task they needed a second set and a 19-register copy per task.  Its node ids are already here
-      // (fetched two tasks ahead), so its nodal gathers leave in the same breath; the ids of the task after it start now.
-      task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(e + stride, n - 1), false);
-      if (GEA) {
-        nxt.nn = nn_ahead;
-        task_fetch_b<IN, GEA>(nxt, P);
-        nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(e + 2 * stride, n - 1)];
-      }
-    }
-    // ---- the two tiles ------------------------------------------------------------------------------------------
-    auto tile_backward = [&](const typename E::template TileAct<L, true>& A, const float (&xt)[3], float gt, bool go_done) {
-      // inputs of the combined tile: (kl lam, kx x, kx y, 1) resp. (kl lam, kx x, 1, 0)
-      unsigned xhi[NPK], xlo[NPK];
-      sfor<2, NPK>([&](auto q) { constexpr int Q = q; xhi[Q] = 0u; xlo[Q] = 0u; });
-      split_pair(kl * xt[0], kx * xt[1], xhi[0], xlo[0]);
-      split_pair(IN == 3 ? kx * xt[2] : 1.0f, IN == 3 ? 1.0f : 0.f, xhi[1], xlo[1]);
-      // (before backward_tile: a'_L is dead there, ten registers less at the kernel's pressure peak)
-      if (!go_done) sfor<0, NR>([&](auto r) { constexpr int R = r; go[R] = fmaf(gt, A.aL[R], go[R]); });
-      if (!(dbg & 2)) E::template backward_tile<L, IN>(smem, scratch, lane, A, gt * S, xhi, xlo, T, wb, rd, dbg);
-    };
-    if constexpr (E::template bw_pair<L>()) {   // recompute both tiles together, then the two back-propagations (see bw_pair)
-      const float x0[3] = {lam_in, xa0, xb0}, x1[3] = {lam_in, xa1, xb1};
-      typename E::template TileAct<L, true> A0, A1;
-      float p0, p1;
-      E::template forward_tiles<L, IN, true>(smem, lane, x0, x1, A0, A1, p0, p1, 0, -1, go, g0, g1);
-      tile_backward(A0, x0, g0, true);
-      tile_backward(A1, x1, g1, true);
-    } else {
-      sfor<0, 2>([&](auto tt) {
-        constexpr int TT = tt;
-        const float xt[3] = {lam_in, TT ? xa1 : xa0, TT ? xb1 : xb0};
-        typename E::template TileAct<L, true> A;
-        E::template recompute_tile<L, IN>(smem, lane, xt, A);
-        tile_backward(A, xt, TT ? g1 : g0, false);
-      });
-    }
-    gbo += gz;
-  }
-  if (lockstep) {
-    // equal barrier counts for the whole block: wave 0 has the longest walk
-    const int base0 = (int)blockIdx.x * waves * 64;
-    const int rounds_b = base0 < n ? (n - 1 - base0) / stride + 1 : 0;
-    const int mine = first_base < n ? (n - 1 - first_base) / stride + 1 : 0;
-    for (int k = mine; k < rounds_b; ++k) __builtin_amdgcn_s_barrier();
-  }
-  if (PF_N32_DBG_ENABLE && stamps) stamps[1] = __builtin_amdgcn_s_memrealtime();
   const float invS = Srun == 0.f ? 1.0f : 1.0f / Srun;
   sfor<0, L>([&](auto l) {
     constexpr int LL = l;
@@ -1954,7 +1465,7 @@ __global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_back
   unsigned char* cst = smem + 2 * IMGPAD;
   unsigned char* wscr = cst + bw2_const_bytes<NRE, NRA>();
   // (diagnostic build, PF_N32_DBG=16: per-wave time stamps into pf_problem.u_alt behind the forward launch's: entry |
-  //  E loop entered | E loop left | E row written | A loop entered | A loop left | A row written)
+  //  E loop entered | E loop left | E row written | A loop entered | A loop left | A row written; tools/fwd2_stamps.py)
   unsigned long long* st = nullptr;
   if (PF_N32_DBG_ENABLE && (dbg & 16) && (threadIdx.x & 63) == 0) {
     st = reinterpret_cast<unsigned long long*>(P.u_alt) + 65536 + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
