@@ -52,6 +52,8 @@ def _sources():
     units += [(f"pf_net32b_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}", "-DPF_PREC=1"] + n32) for r in reversed(NR_BUCKETS)]
     # the fused two-net kernels (E net of bucket r, A net of any bucket): translation units of their own
     fused = ["-DPF_N32_PART=1"]
+    if os.environ.get("PINNFEM_BW_NOPARK", "0") == "1":     # experiment build: block barrier between the fused backward's phases
+        fused.append("-DPF_BW_PARK=0")
     if os.environ.get("PINNFEM_BW2_NOPAIR", "0") == "1":    # experiment build: the fused backward recomputes tile by tile
         fused += ["-DPF_BW_PAIR=0", "-DPF_BW_MAX_THREADS=512"]   # (~190 registers: room for a co-resident memory-bound kernel)
     units += [(f"pf_net32f_{r}.o", "pf_net32.hip", [f"-DPF_NR={r}"] + fused + n32) for r in reversed(NR_BUCKETS)]

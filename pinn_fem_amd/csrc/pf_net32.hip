@@ -1188,14 +1188,99 @@ __device__ __forceinline__ void rows_reduce_last(const pf_problem& P, int nb_row
   stage1_group(P, nb_rows, g, true, false);
 }
 
+// ---- a wave's finished gradient tiles parked in LDS, and the block's row from the parked tiles ---------------------------
+// (the fused two-phase backward launch: a wave that has finished the young net's walk parks its tiles and starts the area
+// net's walk at once instead of waiting at a block barrier for the block's slowest wave; both rows are formed at the end of
+// the launch.  Same values in the same order as the write-out at the end of backward_phase: sums over the waves ascending.)
+// A wave's parking place: [L][1024] tile entries (row m = tile row, 32 columns), then [2][16] output-unit row, then g_bo.
+template <int L>
+constexpr int bw_park_floats() { return L * 1024 + 64; }
+template <int NR, int L>
+__device__ __forceinline__ void bw_park(float* __restrict__ mine, const f32x16 (&T)[L], const float (&go)[NR], float gbo, int lane) {
+  const int h = lane >> 5;
+  sfor<0, L>([&](auto l) {
+    constexpr int LL = l;
+    sfor<0, 16>([&](auto i) {
+      constexpr int I = i;
+      const int m = (I & 3) + 8 * (I >> 2) + 4 * h;      // tile row
+      mine[LL * 1024 + m * 32 + (lane & 31)] = T[LL][I];
+    });
+  });
+  sfor<0, NR>([&](auto r) {
+    constexpr int R = r;
+    float v = go[R];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((lane & 31) == 0) mine[L * 1024 + h * 16 + R] = v;
+  });
+  const float v = pf_wave_sum(gbo);
+  if (lane == 0) mine[L * 1024 + 32] = v;
+}
+// every thread of the block; the caller has placed a block barrier behind the last bw_park.  No barrier inside except the
+// one between the row's zero fill and its entries.
+template <int NR, int L, int IN>
+__device__ __forceinline__ void bw_row_from_parked(const pf_problem& P, int which, int hp, const float* __restrict__ park,
+                                                   float kl, float kx, bool wt) {
+  const pf_net net = P.net[which];
+  const int waves = blockDim.x >> 6, W = net.width;
+  constexpr int PS = bw_park_floats<L>();
+  float* __restrict__ prow = P.partials + PF_PART_WG + (size_t)blockIdx.x * P.pad_total + net.pad_off;
+  const int padc = pf_pad_count(hp, L);
+  for (int i = threadIdx.x; i < padc; i += blockDim.x) row_store(prow + i, 0.f, wt);
+  __syncthreads();
+  sfor<0, L>([&](auto l) {
+    constexpr int LL = l + 1;                      // layer whose weight gradient tile T[LL-1] holds
+    float sc = 1.f;
+    for (int k = 0; k < L - LL; ++k) sc *= 4.f;
+    for (int idx = threadIdx.x; idx < 1024; idx += blockDim.x) {
+      const int m = idx >> 5, c = idx & 31;
+      const int j = 2 * (m & 15) + (m >> 4);
+      if ((m & 15) >= NR || j >= W) continue;
+      float t = 0.f;
+      for (int q = 0; q < waves; ++q) t += park[q * PS + (LL - 1) * 1024 + idx];
+      int dst = -1;
+      float k = sc;
+      if (LL >= 2) {
+        const int kk = 2 * (c & 15) + (c >> 4);
+        k *= PF_N32_KA;
+        if (c == 15) dst = pf_pad_wh(hp, LL) + j * (hp + 4) + hp;                      // bias column
+        else if ((c & 15) < NR && kk < W) dst = pf_pad_wh(hp, LL) + j * (hp + 4) + kk;
+      } else {
+        if (c < IN) { dst = j * 4 + c; k *= c == 0 ? kl : kx; }
+        else if (c == IN) dst = j * 4 + IN;                                           // bias (input 1.0)
+      }
+      if (dst >= 0) row_store(prow + dst, t / k, wt);
+    }
+  });
+  if (threadIdx.x < 32) {
+    const int hh = threadIdx.x >> 4, r = threadIdx.x & 15, u = 2 * r + hh;
+    if (r < NR && u < W) {
+      float t = 0.f;
+      for (int q = 0; q < waves; ++q) t += park[q * PS + L * 1024 + hh * 16 + r];
+      row_store(prow + pf_pad_wo(hp, L) + u, t * (1.0f / PF_N32_KA), wt);
+    }
+  }
+  if (threadIdx.x == 32) {
+    float t = 0.f;
+    for (int q = 0; q < waves; ++q) t += park[q * PS + L * 1024 + 32];
+    row_store(prow + pf_pad_wo(hp, L) + hp, t, wt);
+  }
+}
+
 // One net's backward over the block's tasks, as a phase of a launch: `smem` = this net's operand image in LDS (copied by
 // the caller, no barrier needed before the call), `cst` = the constant blocks (CONST_BYTES of this bucket), `wscr` = the
 // block's wave scratches (the write-out staging reuses them).  Ends with the block's partial gradient row written; the
 // caller places a block barrier between two phases that share cst / wscr.
-template <int NR, int L, int IN, bool GEA>
+// MODE 0: a phase of its own (entry barriers, write-out at its end).  MODE 1 / 2 (fused launch, both buckets in the compact
+// layout: same constant blocks, same scratch size): 1 = first phase, the wave PARKS its tiles in `park` (bw_park) instead
+// of the write-out; 2 = second phase entered WITHOUT a block barrier (constant blocks and images are in place since phase
+// 1; the wave's scratch is its own), at its end: block barrier, `first_row()` (the first phase's row from the parked tiles),
+// block barrier, park, block barrier, own row.
+template <int NR, int L, int IN, bool GEA, int MODE = 0, class FirstRow = int>
 __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, int hp, int dbg, const unsigned char* smem,
                                                unsigned char* cst, unsigned char* wscr, bool wt = false,
-                                               unsigned long long* stamps = nullptr) {
+                                               unsigned long long* stamps = nullptr, float* park = nullptr,
+                                               FirstRow first_row = FirstRow()) {
   using E = Eng<NR>;
   constexpr int CONST_BYTES = E::CONST_BYTES, WAVE_SCRATCH = E::WAVE_SCRATCH, REGION = E::REGION, NPK = E::NPK;
   constexpr bool COMPACT = E::COMPACT;
@@ -1209,11 +1294,12 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, waves = blockDim.x >> 6;
   const int h = lane >> 5;
   unsigned char* scratch = wscr + wv * WAVE_SCRATCH;
-  for (int i = threadIdx.x; i < CONST_BYTES / 4; i += blockDim.x) reinterpret_cast<unsigned*>(cst)[i] = 0u;
+  if constexpr (MODE != 2)
+    for (int i = threadIdx.x; i < CONST_BYTES / 4; i += blockDim.x) reinterpret_cast<unsigned*>(cst)[i] = 0u;
   for (int i = lane; i < WAVE_SCRATCH / 16; i += 64) reinterpret_cast<uint4*>(scratch)[i] = make_uint4(0, 0, 0, 0);
-  __syncthreads();
+  if constexpr (MODE != 2) __syncthreads();
   // bias block: [element/4][half-wave][element%4] x (registers 12..15 as f16): KA in register 15 of the lower half-wave
-  if (threadIdx.x < 32)
+  if (MODE != 2 && threadIdx.x < 32)
     if constexpr (COMPACT)
       *reinterpret_cast<unsigned short*>(cst + 192 + REGION + 64 * (threadIdx.x >> 2) + 8 * (threadIdx.x & 3) + 6) = BF ? 0x4500 : 0x6800;   // 2048.0
   const unsigned char* rd = E::operand_base(scratch, lane, cst + 192);
@@ -1227,7 +1313,7 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
     task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(base + lane, n - 1));
     if (GEA) nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(base + stride + lane, n - 1)];
   }
-  __syncthreads();                               // (image, constant blocks and scratch are in place)
+  if constexpr (MODE != 2) __syncthreads();      // (image, constant blocks and scratch are in place)
   task_fetch_b<IN, GEA>(nxt, P);
 
   // block-uniform scalars: keep them in SGPRs (the kernel runs at its register budget)
@@ -1344,6 +1430,20 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
     constexpr int LL = l;
     sfor<0, 16>([&](auto i) { constexpr int I = i; T[LL][I] *= invS; });
   });
+  if constexpr (MODE == 1) {
+    bw_park<NR, L>(park + (size_t)wv * bw_park_floats<L>(), T, go, gbo, lane);
+    if (PF_N32_DBG_ENABLE && stamps) stamps[2] = __builtin_amdgcn_s_memrealtime();
+    return;
+  } else if constexpr (MODE == 2) {
+    __syncthreads();                               // every wave of the block has parked its first-phase tiles and left both loops
+    first_row();
+    __syncthreads();                               // the parked tiles are read
+    bw_park<NR, L>(park + (size_t)wv * bw_park_floats<L>(), T, go, gbo, lane);
+    __syncthreads();
+    bw_row_from_parked<NR, L, IN>(P, which, hp, park, kl, kx, wt);
+    if (PF_N32_DBG_ENABLE && stamps) stamps[2] = __builtin_amdgcn_s_memrealtime();
+    return;
+  }
 
   // ---- write-out: fixed-order sums over the block's waves -> this block's partial gradient row ---------------------------
   __syncthreads();
@@ -1449,6 +1549,19 @@ constexpr int bw2_const_bytes() { return Eng<NRE>::CONST_BYTES > Eng<NRA>::CONST
 template <int NRE, int NRA>
 constexpr int bw2_wave_scratch() { return Eng<NRE>::WAVE_SCRATCH > Eng<NRA>::WAVE_SCRATCH ? Eng<NRE>::WAVE_SCRATCH : Eng<NRA>::WAVE_SCRATCH; }
 
+// the phases run without a barrier between them (parked tiles) where both buckets use the compact LDS layout (same constant
+// blocks, same scratch) and the block's LDS has room for the parking places; PF_BW_PARK=0: experiment build (barrier form)
+#ifndef PF_BW_PARK
+#define PF_BW_PARK 1
+#endif
+template <int NRE, int NRA>
+constexpr bool bw2_parked() { return PF_BW_PARK && Eng<NRE>::COMPACT && Eng<NRA>::COMPACT; }
+template <int NRE, int NRA, int L, int IN>
+constexpr size_t bw2_lds_bytes() {
+  return 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255) + bw2_const_bytes<NRE, NRA>() +
+         (size_t)(bw2_threads<NRE, NRA, L, IN>() / 64) * bw2_wave_scratch<NRE, NRA>() +
+         (bw2_parked<NRE, NRA>() ? (size_t)(bw2_threads<NRE, NRA, L, IN>() / 64) * bw_park_floats<L>() * sizeof(float) : 0);
+}
 template <int NRE, int NRA, int L, int IN>
 __global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_backward2(pf_problem P, int hp_e, int hp_a, int dbg_arg,
                                                                                      int reduce_rows) {
@@ -1471,9 +1584,19 @@ __global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_back
     st = reinterpret_cast<unsigned long long*>(P.u_alt) + 65536 + (size_t)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 8;
     st[0] = t_entry;
   }
-  backward_phase<NRE, L, IN, true>(P, 0, hp_e, dbg, smem, cst, wscr, reduce_rows != 0, st ? st + 1 : nullptr);
-  __syncthreads();                               // the write-out staging of phase 1 is read; scratch and constants are re-initialised
-  backward_phase<NRA, L, IN, false>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr, reduce_rows != 0, st ? st + 4 : nullptr);
+  if constexpr (bw2_parked<NRE, NRA>()) {
+    // no barrier between the phases: a wave parks its young-net tiles and walks on (see backward_phase, MODE)
+    float* park = reinterpret_cast<float*>(wscr + (size_t)(blockDim.x >> 6) * bw2_wave_scratch<NRE, NRA>());
+    const float kl_e = pf_n32_lam_scale(P.lam), kx_e = __builtin_ldexpf(1.0f, P.coord_exp);
+    const bool wt = reduce_rows != 0;
+    auto first_row = [&]() { bw_row_from_parked<NRE, L, IN>(P, 0, hp_e, park, kl_e, kx_e, wt); };
+    backward_phase<NRE, L, IN, true, 1>(P, 0, hp_e, dbg, smem, cst, wscr, wt, st ? st + 1 : nullptr, park);
+    backward_phase<NRA, L, IN, false, 2>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr, wt, st ? st + 4 : nullptr, park, first_row);
+  } else {
+    backward_phase<NRE, L, IN, true>(P, 0, hp_e, dbg, smem, cst, wscr, reduce_rows != 0, st ? st + 1 : nullptr);
+    __syncthreads();                             // the write-out staging of phase 1 is read; scratch and constants are re-initialised
+    backward_phase<NRA, L, IN, false>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr, reduce_rows != 0, st ? st + 4 : nullptr);
+  }
   // reduce_rows: the launch is also theta stage 1 (the last block of every row group sums the group's rows)
   if (reduce_rows) rows_reduce_last(P, (int)gridDim.x);
 }
@@ -1553,8 +1676,8 @@ int launch_bwd2_t(const pf_problem* p, hipStream_t s, int reduce_rows) {
   const int nb = pf_net_blocks(p);
   const int hp_e = ((p->net[0].width + 3) / 4) * 4, hp_a = ((p->net[1].width + 3) / 4) * 4;
   constexpr int THREADS = bw2_threads<NRE, NRA, L, IN>();
-  const size_t lds = 2 * (size_t)((pf_n32_bytes(L) + 255) & ~255) + bw2_const_bytes<NRE, NRA>() +
-                     (size_t)(THREADS / 64) * bw2_wave_scratch<NRE, NRA>();
+  const size_t lds = bw2_lds_bytes<NRE, NRA, L, IN>();
+  static_assert(bw2_lds_bytes<NRE, NRA, L, IN>() <= 160 * 1024, "fused backward: LDS budget");
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;
   hipLaunchKernelGGL((k_net32_backward2<NRE, NRA, L, IN>), dim3(nb), dim3(THREADS), lds, s, *p, hp_e, hp_a, dbg, reduce_rows);
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
