@@ -1280,7 +1280,7 @@ template <int NR, int L, int IN, bool GEA, int MODE = 0, class FirstRow = int>
 __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, int hp, int dbg, const unsigned char* smem,
                                                unsigned char* cst, unsigned char* wscr, bool wt = false,
                                                unsigned long long* stamps = nullptr, float* park = nullptr,
-                                               FirstRow first_row = FirstRow()) {
+                                               FirstRow first_row = FirstRow(), int shift8 = 0) {
   using E = Eng<NR>;
   constexpr int CONST_BYTES = E::CONST_BYTES, WAVE_SCRATCH = E::WAVE_SCRATCH, REGION = E::REGION, NPK = E::NPK;
   constexpr bool COMPACT = E::COMPACT;
@@ -1305,13 +1305,33 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
   const unsigned char* rd = E::operand_base(scratch, lane, cst + 192);
   const WriteBase wb = E::write_base(scratch, lane);
 
-  const int stride = gridDim.x * waves * 64;
-  int base = (blockIdx.x * waves + wv) * 64;
+  // Which 64-element tasks the wave walks: its own column of the round-robin (task = round * waves of the launch + the
+  // wave's slot), and — shift8 > 0 — a handicap between the two waves of a SIMD (w and w + waves/2): the SIMD arbitrates by
+  // age, the older wave (lower id) runs nearly unimpeded and left alone finishes its walk long before the younger one, which
+  // then does its last tasks alone with nothing to hide its latencies behind (time stamps: the waves of one block leave a
+  // loop up to 14 us apart).  So the older wave also takes the LAST shift8/8 of the younger wave's column.  A fixed
+  // assignment: the sums stay reproducible, and the same in both phases of the fused launch (a wave reads back the element
+  // adjoints it wrote itself).
+  const int per_round = (int)gridDim.x * waves;
+  const int ntasks_all = (n + 63) >> 6;
+  const int slot = (int)blockIdx.x * waves + wv;
+  const int hw = waves >> 1;
+  const bool elder = wv < hw;
+  const int partner = elder ? slot + hw : slot - hw;
+  const int c_own = slot < ntasks_all ? (ntasks_all - 1 - slot) / per_round + 1 : 0;
+  const int c_par = (hw > 0 && partner < ntasks_all) ? (ntasks_all - 1 - partner) / per_round + 1 : 0;
+  const int sh = (shift8 > 0 && hw > 0 && (waves & 1) == 0) ? (((elder ? c_par : c_own) * shift8 + 4) >> 3) : 0;
+  const int n_mine = elder ? c_own + sh : c_own - sh;
+  auto task_base = [&](int k) {                  // element base of the wave's k-th task; past its last one: the last element
+    if (k < (elder ? c_own : n_mine)) return (k * per_round + slot) * 64;
+    if (elder && k < n_mine) return ((c_par - sh + (k - c_own)) * per_round + partner) * 64;
+    return n - 1;
+  };
   TaskIn<DIM> nxt;
   int2 nn_ahead = int2{0, 0};                    // node ids of the task after next (GEA only)
   if (n > 0) {
-    task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(base + lane, n - 1));
-    if (GEA) nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(base + stride + lane, n - 1)];
+    task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(task_base(0) + lane, n - 1));
+    if (GEA) nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(task_base(1) + lane, n - 1)];
   }
   if constexpr (MODE != 2) __syncthreads();      // (image, constant blocks and scratch are in place)
   task_fetch_b<IN, GEA>(nxt, P);
@@ -1331,11 +1351,12 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
   float gbo = 0.f;      // sum over own elements of g_z
 
   if (PF_N32_DBG_ENABLE && stamps) stamps[0] = __builtin_amdgcn_s_memrealtime();
-  for (; base < n; base += stride) {
+  for (int k = 0; k < n_mine; ++k) {
+    const int base = task_base(k);
     const int e = base + lane;
     const bool live = e < n;
     const TaskIn<DIM> cur = nxt;
-    const bool more = base + stride < n;
+    const bool more = k + 1 < n_mine;
     // ---- per-element scalars: one element per lane ----------------------------------------------------------
     // softplus'(z) = sigmoid(z) = 1 - exp(-softplus(z)) from the forward's stored value (= softplus(z) * scale), so the
     // output unit need not be recomputed (torch: z > 20 ? 1 : e^z / (e^z + 1), the same number to float round-off)
@@ -1388,11 +1409,11 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
       // tiles below work on derived values only), so the new values can land in the registers the old ones held — issued
       // at the top of the task they needed a second set and a 19-register copy per task.  Its node ids are already here
       // (fetched two tasks ahead), so its nodal gathers leave in the same breath; the ids of the task after it start now.
-      task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(e + stride, n - 1), false);
+      task_fetch_a<IN, GEA>(nxt, P, onet, other, mine, min(task_base(k + 1) + lane, n - 1), false);
       if (GEA) {
         nxt.nn = nn_ahead;
         task_fetch_b<IN, GEA>(nxt, P);
-        nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(e + 2 * stride, n - 1)];
+        nn_ahead = reinterpret_cast<const int2*>(P.mesh.conn)[min(task_base(k + 2) + lane, n - 1)];
       }
     }
     // ---- the two tiles ------------------------------------------------------------------------------------------
@@ -1588,17 +1609,20 @@ __global__ __launch_bounds__((bw2_threads<NRE, NRA, L, IN>())) void k_net32_back
     // no barrier between the phases: a wave parks its young-net tiles and walks on (see backward_phase, MODE)
     float* park = reinterpret_cast<float*>(wscr + (size_t)(blockDim.x >> 6) * bw2_wave_scratch<NRE, NRA>());
     const float kl_e = pf_n32_lam_scale(P.lam), kx_e = __builtin_ldexpf(1.0f, P.coord_exp);
-    const bool wt = reduce_rows != 0;
+    const bool wt = (reduce_rows & 1) != 0;
     auto first_row = [&]() { bw_row_from_parked<NRE, L, IN>(P, 0, hp_e, park, kl_e, kx_e, wt); };
-    backward_phase<NRE, L, IN, true, 1>(P, 0, hp_e, dbg, smem, cst, wscr, wt, st ? st + 1 : nullptr, park);
-    backward_phase<NRA, L, IN, false, 2>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr, wt, st ? st + 4 : nullptr, park, first_row);
+    backward_phase<NRE, L, IN, true, 1>(P, 0, hp_e, dbg, smem, cst, wscr, wt, st ? st + 1 : nullptr, park, 0, reduce_rows >> 1);
+    backward_phase<NRA, L, IN, false, 2>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr, wt, st ? st + 4 : nullptr, park, first_row,
+                                         reduce_rows >> 1);
   } else {
-    backward_phase<NRE, L, IN, true>(P, 0, hp_e, dbg, smem, cst, wscr, reduce_rows != 0, st ? st + 1 : nullptr);
+    backward_phase<NRE, L, IN, true>(P, 0, hp_e, dbg, smem, cst, wscr, (reduce_rows & 1) != 0, st ? st + 1 : nullptr, nullptr, 0,
+                                     reduce_rows >> 1);
     __syncthreads();                             // the write-out staging of phase 1 is read; scratch and constants are re-initialised
-    backward_phase<NRA, L, IN, false>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr, reduce_rows != 0, st ? st + 4 : nullptr);
+    backward_phase<NRA, L, IN, false>(P, 1, hp_a, dbg, smem + IMGPAD, cst, wscr, (reduce_rows & 1) != 0, st ? st + 4 : nullptr,
+                                      nullptr, 0, reduce_rows >> 1);
   }
   // reduce_rows: the launch is also theta stage 1 (the last block of every row group sums the group's rows)
-  if (reduce_rows) rows_reduce_last(P, (int)gridDim.x);
+  if (reduce_rows & 1) rows_reduce_last(P, (int)gridDim.x);
 }
 
 template <int L, int IN>
@@ -1679,7 +1703,10 @@ int launch_bwd2_t(const pf_problem* p, hipStream_t s, int reduce_rows) {
   const size_t lds = bw2_lds_bytes<NRE, NRA, L, IN>();
   static_assert(bw2_lds_bytes<NRE, NRA, L, IN>() <= 160 * 1024, "fused backward: LDS budget");
   static const int dbg = getenv("PF_N32_DBG") ? atoi(getenv("PF_N32_DBG")) : 0;
-  hipLaunchKernelGGL((k_net32_backward2<NRE, NRA, L, IN>), dim3(nb), dim3(THREADS), lds, s, *p, hp_e, hp_a, dbg, reduce_rows);
+  // PF_BW_SHIFT: eighths of the younger wave's tasks the older wave of its SIMD takes over (backward_phase, shift8; bits 1..
+  // of the kernel's reduce_rows argument)
+  static const int shift8 = getenv("PF_BW_SHIFT") ? atoi(getenv("PF_BW_SHIFT")) : 2;     // measured best of 0..3 (r03_ab.txt)
+  hipLaunchKernelGGL((k_net32_backward2<NRE, NRA, L, IN>), dim3(nb), dim3(THREADS), lds, s, *p, hp_e, hp_a, dbg, (reduce_rows ? 1 : 0) | (shift8 << 1));
   return hipGetLastError() == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 template <int L, int IN>
