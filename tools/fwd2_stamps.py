@@ -42,3 +42,9 @@ if len(rawb):
         endb = blkb[:, :, 6].max(1)
         print("blocks end: min", endb.min().round(2), "med", np.median(endb).round(2), "max", endb.max().round(2),
               "| first 160 blocks med", np.median(endb[:160]).round(2), "| last 90 blocks med", np.median(endb[-90:]).round(2))
+        a_out = blkb[:, :, 5]
+        print("A loop left, per block: spread (max - min over its 8 waves) med", np.median(a_out.max(1) - a_out.min(1)).round(2),
+              "| elder waves (0-3) med", np.median(a_out[:, :4]).round(2), "| younger (4-7) med", np.median(a_out[:, 4:]).round(2))
+        e_out = blkb[:, :, 2]
+        print("E loop left: elder med", np.median(e_out[:, :4]).round(2), "| younger med", np.median(e_out[:, 4:]).round(2))
+        print("per wave id, A loop left med:", [float(np.median(a_out[:, w]).round(1)) for w in range(8)])
