@@ -216,13 +216,14 @@ def side_config(workload, n_elems, dev, steps, mesh="chain"):
                        learning_rate_theta=5e-4 if workload == "ex4" else 1e-3)
     eng = HipEngine(model, mv, md, device=dev)
     eng.begin(None, 0.1, cfg, want_history=False)
-    eng.prepare_graph()
-    eng.iterate(eng.GRAPH_ITERS)
+    eng.prepare_graph(chained=True)
+    eng.iterate(eng.GRAPH_ITERS, defer_tail=True)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    eng.iterate(steps)
+    eng.iterate(steps, defer_tail=True)      # chained replays, like solve_gd's loop (the tail is paid once, by flush())
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    eng.flush()
     return {"value": n_elems * steps / dt, "unit": "element-evals/s", "ms_per_step": dt / steps * 1e3,
             "steps": steps}
 
@@ -298,15 +299,19 @@ def main():
         model, mv, md, widths = build_model(n_local, args.workload)
         eng = HipEngine(model, mv, md, device=dev)
         eng.begin(None, 0.1, cfg, want_history=False)
-        eng.prepare_graph()                           # capture + instantiate: never inside the timed region
+        eng.prepare_graph(chained=True)               # capture + instantiate: never inside the timed region
         gk = eng.GRAPH_ITERS
         # >= W, whole replays (the graph is uploaded and hot), and at least 50 iterations (~8 ms): the chip's clocks are still
         # settling during the first replays after the event pass (the first 20-step region read 3-5 us per step above the
         # following ones); the number actually run is reported as warmup_iterations_run
         n_warm = ((max(args.warmup, 50) + gk - 1) // gk) * gk
-        run_warm = lambda n: eng.iterate(n)
-        run_timed = lambda n: eng.iterate(n)          # hipGraph replay (10 iterations per graph)
-        run_events = lambda n: eng.iterate_timed(n)   # eager launches with HIP events around every kernel
+        # chained replays, as in solve_gd's loop: a replay hands the updates and the bookkeeping of its last iteration to
+        # the next replay's first one (every iteration of a replay carries its predecessor's anyway); each replay of K
+        # iterations still does K forward / residual / backward passes, K parameter and displacement updates and K
+        # bookkeeping steps.  flush() pays the one pending tail before the state is read.
+        run_warm = lambda n: eng.iterate(n, defer_tail=True)
+        run_timed = lambda n: eng.iterate(n, defer_tail=True)     # hipGraph replays (20 iterations per graph at 10^6 elements)
+        run_events = lambda n: (eng.flush(), eng.iterate_timed(n))[1]   # eager launches with HIP events around every kernel
         graph_count = lambda: eng.graph_creates
     else:
         from pinn_fem_amd.dist import ShardedChainEngine
@@ -358,6 +363,8 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    if world == 1:
+        eng.flush()                          # (outside the timed region: the one pending tail of the chained replays)
     st = eng.state()
     assert st.iter == iters_before + n_warm + args.steps, (st.iter, iters_before + n_warm + args.steps)
     assert graph_count() == graphs_before, "a hipGraph was captured inside the timed region"

@@ -281,6 +281,18 @@ int pf_gd_iterations(const pf_problem* p, int n_iter, void* stream);
  * the other half of the residual's partial sums (part_half); the last iteration of a replay gets a stand-alone
  * pf_finalize.  Results are bit-identical to pf_gd_iterations. */
 int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void** graph_out);
+/* Replays that hand their last iteration's tail to the next replay (one-chain form of the graph only, even
+ * iters_per_graph; PF_ERR_UNSUPPORTED otherwise).  A plain replay ends with three stand-alone launches — the parameter
+ * update, the displacement update and the bookkeeping of its last iteration (~45 us at 10^6 elements).  PF_GRAPH_NO_TAIL
+ * leaves them PENDING behind the last gradient-row reduction; PF_GRAPH_CONT_HEAD makes iteration 0 carry the pending work of
+ * the replay before it (as every other iteration of a replay carries its predecessor's).  Sequence: [NO_TAIL] then any
+ * number of [CONT_HEAD | NO_TAIL], then pf_graph_tail (eager launches) before anything reads the state; a stop raised on
+ * the device is honoured as in a plain replay (solver.py:341-355 semantics: the final state is that of the stopping
+ * iteration). */
+#define PF_GRAPH_CONT_HEAD 1
+#define PF_GRAPH_NO_TAIL 2
+int pf_graph_create_ex(const pf_problem* p, int iters_per_graph, int flags, void* stream, void** graph_out);
+int pf_graph_tail(const pf_problem* p, int iters_per_graph, void* stream);
 int pf_graph_launch(void* graph, void* stream);
 int pf_graph_destroy(void* graph);
 /* Profiling twin of pf_gd_iterations: same launches with a HIP event before every kernel slot, then

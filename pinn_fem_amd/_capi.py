@@ -25,6 +25,7 @@ PF_COMM_ID_BYTES = 128
 PF_MAX_NODE_BLOCKS = 4096
 PF_NODE_SLOTS = PF_MAX_NODE_BLOCKS + 8
 PF_KERNEL_SLOTS = 9
+PF_GRAPH_CONT_HEAD, PF_GRAPH_NO_TAIL = 1, 2
 PF_FUSED_FORWARD, PF_FUSED_BACKWARD, PF_FUSED_THETA_UPDATE, PF_FUSED_U_PINGPONG, PF_FUSED_U_UPDATE = 1, 2, 4, 8, 16
 KERNEL_SLOT_NAMES = ("net_forward_young", "net_forward_area", "node_residual", "elem_adjoint",
                      "net_backward_young", "net_backward_area", "node_gradu_adam", "theta_reduce_adam",
@@ -125,6 +126,8 @@ SYMBOLS = {
     "pf_reset": (C.c_int, [_PP, C.c_void_p]),
     "pf_gd_iterations": (C.c_int, [_PP, C.c_int, C.c_void_p]),
     "pf_graph_create": (C.c_int, [_PP, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pf_graph_create_ex": (C.c_int, [_PP, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pf_graph_tail": (C.c_int, [_PP, C.c_int, C.c_void_p]),
     "pf_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pf_graph_destroy": (C.c_int, [C.c_void_p]),
     "pf_gd_iterations_timed": (C.c_int, [_PP, C.c_int, C.c_void_p, C.POINTER(C.c_float)]),

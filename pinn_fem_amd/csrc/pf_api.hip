@@ -540,7 +540,11 @@ static bool pad_index_is_canonical(const pf_problem* p) {
   return same;
 }
 
-static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_capture& c, bool calc_index = false) {
+// head_cont: iteration 0 also carries the updates and the bookkeeping of the iteration BEFORE the replay (left pending by a
+// no_tail replay); no_tail: the replay ends behind the last iteration's gradient-row reduction, its parameter update,
+// displacement update and bookkeeping stay pending (pf_graph_create_ex).  Both only in the one-chain form.
+static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_capture& c, bool calc_index = false,
+                                    bool head_cont = false, bool no_tail = false) {
   const bool any_net = p->net[0].enabled || p->net[1].enabled;
   hipStream_t s = c.s;
   // PF_GRAPH_SERIAL=1: experiment knob, the plain chain of launches inside the graph (no branches)
@@ -611,10 +615,11 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     if (i > 0 && !pingpong && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
     // (both nets in one launch where the engine has it; else one after the other: side by side on two branches they
     // measured slower, the same issue pipe, and the second one writes the stiffness records from both)
+    const bool carries = i > 0 || head_cont;      // this iteration's forward / residual carry the previous iteration's work
     const float* k_prev = nullptr;        // the records iteration i-1 wrote (the other half)
-    if (fuse_gu && i > 0) k_prev = ((i - 1) & 1) ? c_elem_k + (size_t)q.mesh.n_elems * (q.mesh.dim == 2 ? 3 : 1) : c_elem_k;
+    if (fuse_gu && carries) k_prev = ((i - 1) & 1) ? c_elem_k + (size_t)q.mesh.n_elems * (q.mesh.dim == 2 ? 3 : 1) : c_elem_k;
     pf_fwd2_opts fo;
-    if (fuse_s2 && i > 0) fo.s2_half = (i - 1) & 1;
+    if (fuse_s2 && carries) fo.s2_half = (i - 1) & 1;       // (i = 0 in a continuation: the previous replay's last = half 1)
     fo.calc_index = calc_index;
     if (k_prev) {
       fo.gu_nb = pf_node_blocks(q.mesh.n_nodes);
@@ -624,7 +629,7 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
     // residual(i) reads u(i) [gradu(i-1)]; its block 0 is finalize(i-1): behind the theta update of i-1 (this chain:
     // the forward launch above, or the stand-alone kernel) and gradu(i-1)
     if (i > 0 && !ev_wait(s, ep[1])) return fail(PF_ERR_HIP, "graph edge failed");
-    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, i > 0 ? (tn_ready ? 2 : 1) : 0), "node_residual");
+    PF_TRY(pf_launch_node_residual(p, nullptr, 1, s, carries ? (tn_ready ? 2 : 1) : 0), "node_residual");
     if (upp && !ev_rec(e[0], s)) return fail(PF_ERR_HIP, "graph edge failed");      // gradu forks here
     if (!fuse_gea) {
       PF_TRY(pf_launch_elem_adjoint(p, s), "elem_adjoint");
@@ -642,14 +647,15 @@ static int enqueue_graph_iterations(const pf_problem* p, int iters, const pf_cap
       }
     }
     if (!(can_fuse_backward(p) && fuse_s1_knob())) PF_TRY(pf_launch_theta_stage1(p, s), "theta_stage1");
-    if (!fuse_s2 || i == iters - 1) PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
+    if (!fuse_s2 || (i == iters - 1 && !no_tail)) PF_TRY(pf_launch_theta_stage2(p, 1, s), "theta_stage2");
     // branch A (created after the main chain's nodes of this iteration): gradu behind the last reader of u
-    if (fuse_gu && i < iters - 1) continue;           // (the next forward launch carries it)
+    if (fuse_gu && (i < iters - 1 || no_tail)) continue;   // (the next forward launch carries it)
     if (!ev_wait(sa, e[0])) return fail(PF_ERR_HIP, "graph edge failed");
     PF_TRY(pf_launch_node_gradu(p, 1, sa, 0, u_next), "node_gradu");
     if (!ev_rec(e[1], sa)) return fail(PF_ERR_HIP, "graph edge failed");
   }
   // finalize of the last iteration: behind stage 2 (this chain) and the last gradu
+  if (no_tail) return PF_OK;
   if (!serial && !ev_wait(s, c.ev[PF_CAP_EV * (iters - 1) + 1])) return fail(PF_ERR_HIP, "graph join failed");
   if (upp) PF_TRY(pf_launch_u_home(p, s), "u_home");      // (only a stop in mid-replay leaves anything to copy)
   {
@@ -720,6 +726,46 @@ int pf_graph_create(const pf_problem* p, int iters_per_graph, void* stream, void
   const bool calc_index = ci_knob != 0 && can_fuse_theta_update(p) && pad_index_is_canonical(p);
   return capture_graph((hipStream_t)stream, PF_CAP_EV * iters_per_graph, hipStreamCaptureModeThreadLocal, graph_out,
                        [&](pf_capture& cap) { return enqueue_graph_iterations(p, iters_per_graph, cap, calc_index); });
+}
+
+// can the iteration graph of this problem be cut into replays that hand their last iteration's updates to the next one?
+static bool can_chain_replays(const pf_problem* p, int iters) {
+  static const bool pp_knob = !(getenv("PF_GRAPH_PINGPONG") && atoi(getenv("PF_GRAPH_PINGPONG")) == 0);
+  return (iters % 2) == 0 && p->prop_double != 0 && pp_knob && p->elem_k != nullptr && can_fuse_gradu(p) &&
+         can_fuse_theta_update(p);
+}
+
+int pf_graph_create_ex(const pf_problem* p, int iters_per_graph, int flags, void* stream, void** graph_out) {
+  int rc = check_gd(p);
+  if (rc) return rc;
+  if (!graph_out || iters_per_graph < 1) return fail(PF_ERR_ARG, "pf_graph_create_ex: bad argument");
+  if ((flags & (PF_GRAPH_CONT_HEAD | PF_GRAPH_NO_TAIL)) && !can_chain_replays(p, iters_per_graph))
+    return fail(PF_ERR_UNSUPPORTED, "pf_graph_create_ex: replays of this problem's graph cannot hand over their tail");
+  static const int ci_knob = getenv("PF_CALC_INDEX") ? atoi(getenv("PF_CALC_INDEX")) : 1;
+  const bool calc_index = ci_knob != 0 && can_fuse_theta_update(p) && pad_index_is_canonical(p);
+  const bool head = (flags & PF_GRAPH_CONT_HEAD) != 0, no_tail = (flags & PF_GRAPH_NO_TAIL) != 0;
+  return capture_graph((hipStream_t)stream, PF_CAP_EV * iters_per_graph, hipStreamCaptureModeThreadLocal, graph_out,
+                       [&](pf_capture& cap) { return enqueue_graph_iterations(p, iters_per_graph, cap, calc_index, head, no_tail); });
+}
+
+// the pending tail of a PF_GRAPH_NO_TAIL replay: what the last iteration of a plain replay ends with
+int pf_graph_tail(const pf_problem* p, int iters_per_graph, void* stream) {
+  int rc = check_gd(p);
+  if (rc) return rc;
+  if (!can_chain_replays(p, iters_per_graph)) return fail(PF_ERR_UNSUPPORTED, "pf_graph_tail: not a chained replay");
+  hipStream_t s = (hipStream_t)stream;
+  pf_problem q = *p;                      // the last iteration's halves (iters even: the second ones)
+  const int i = iters_per_graph - 1;
+  if (i & 1) {
+    q.prop_e += q.mesh.n_elems;
+    q.prop_a += q.mesh.n_elems;
+    if (q.elem_k) q.elem_k += (size_t)q.mesh.n_elems * (q.mesh.dim == 2 ? 3 : 1);
+  }
+  q.part_half = i & 1;
+  PF_TRY(pf_launch_theta_stage2(&q, 1, s), "theta_stage2");
+  PF_TRY(pf_launch_node_gradu(&q, 1, s, 0, nullptr), "node_gradu");
+  PF_TRY(pf_launch_finalize(&q, 0, 0, s, q.wg_mode == PF_WG_MFMA32 ? 1 : 0), "finalize");
+  return PF_OK;
 }
 
 int pf_graph_launch(void* graph, void* stream) {

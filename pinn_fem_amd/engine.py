@@ -287,6 +287,7 @@ class HipEngine:
                 np.asarray(u_initial))
             self.u.copy_(src.reshape(-1).to(device=self.device, dtype=torch.float32))
         s = self._stream()
+        self._pending_tail = False          # (a new solve: nothing of the previous one is pending)
         _capi.check(self.lib.pf_reset(self._ref(), s), "pf_reset")
         _capi.check(self.lib.pf_pack_theta(self._ref(), s), "pf_pack_theta")
 
@@ -302,37 +303,79 @@ class HipEngine:
         if g:
             self.lib.pf_graph_destroy(g)
         self._graph = None
+        for h in getattr(self, "_chain_graphs", {}).values():
+            if h:
+                self.lib.pf_graph_destroy(h)
+        self._chain_graphs = {}
 
     graph_creates = 0        # hipGraph captures + instantiations so far (bench.py asserts none is timed)
+    _pending_tail = False    # a chained replay has left its last iteration's updates / bookkeeping pending (see iterate)
 
     @_on_engine_stream
-    def prepare_graph(self):
+    def prepare_graph(self, chained: bool = False):
         """Capture and instantiate the iteration hipGraph of the current pf_problem record now (it is
-        otherwise created by the first iterate() call that replays it).  Enqueues no iteration."""
+        otherwise created by the first iterate() call that replays it).  Enqueues no iteration.
+        chained: also the two graphs of chained replays (iterate(defer_tail=True)); returns whether the problem has them."""
         if getattr(self, "_graph", None) is None:
             g = C.c_void_p()
             _capi.check(self.lib.pf_graph_create(self._ref(), self.GRAPH_ITERS, self._stream(), C.byref(g)),
                         "pf_graph_create")
             self._graph = g
             self.graph_creates += 1
+        if not chained:
+            return True
+        if not hasattr(self, "_chain_graphs"):
+            self._chain_graphs = {}
+        for flags in (_capi.PF_GRAPH_NO_TAIL, _capi.PF_GRAPH_NO_TAIL | _capi.PF_GRAPH_CONT_HEAD):
+            if flags not in self._chain_graphs:
+                g = C.c_void_p()
+                rc = self.lib.pf_graph_create_ex(self._ref(), self.GRAPH_ITERS, flags, self._stream(), C.byref(g))
+                if rc == _capi.PF_ERR_UNSUPPORTED:
+                    self._chain_graphs[flags] = None        # (not the one-chain form: plain replays)
+                    continue
+                _capi.check(rc, "pf_graph_create_ex")
+                self._chain_graphs[flags] = g
+                self.graph_creates += 1
+        return all(self._chain_graphs.get(f) for f in (2, 3))
 
     @_on_engine_stream
-    def iterate(self, n_iter: int, use_graph: Optional[bool] = None):
+    def flush(self):
+        """Run the pending tail of chained replays (parameter update, displacement update and bookkeeping of the last
+        iteration).  iterate() calls it before anything but another chained replay; call it before reading the state."""
+        if self._pending_tail:
+            _capi.check(self.lib.pf_graph_tail(self._ref(), self.GRAPH_ITERS, self._stream()), "pf_graph_tail")
+            self._pending_tail = False
+
+    @_on_engine_stream
+    def iterate(self, n_iter: int, use_graph: Optional[bool] = None, defer_tail: bool = False):
         """Enqueue n_iter GD iterations.  Whole multiples of GRAPH_ITERS replay a captured hipGraph
         (created lazily per begin(), or ahead of time by prepare_graph(); the graph bakes in the current
         pf_problem record), the remainder is launched eagerly.  Launches after the device-side stop are
-        no-ops either way."""
+        no-ops either way.
+        defer_tail: the replays are CHAINED where the problem allows it — a replay ends behind its last gradient-row
+        reduction and the next replay's first iteration carries that iteration's updates and bookkeeping, like every other
+        iteration of a replay carries its predecessor's; the ~45 us of stand-alone launches a plain replay ends with are
+        paid once, by flush().  state() / history() / u / theta lag by that one iteration until flush()."""
         n_iter = int(n_iter)
         if use_graph is None:
             use_graph = os.environ.get("PINNFEM_GRAPH", "1") != "0"
         s = self._stream()
         k = self.GRAPH_ITERS
         if use_graph and n_iter >= k:
-            self.prepare_graph()
+            chained = defer_tail and self.prepare_graph(chained=True)
+            if not chained:
+                self.flush()
+                self.prepare_graph()
             while n_iter >= k:
-                _capi.check(self.lib.pf_graph_launch(self._graph, s), "pf_graph_launch")
+                if chained:
+                    g = self._chain_graphs[3 if self._pending_tail else 2]
+                    _capi.check(self.lib.pf_graph_launch(g, s), "pf_graph_launch")
+                    self._pending_tail = True
+                else:
+                    _capi.check(self.lib.pf_graph_launch(self._graph, s), "pf_graph_launch")
                 n_iter -= k
         if n_iter > 0:
+            self.flush()
             _capi.check(self.lib.pf_gd_iterations(self._ref(), n_iter, s), "pf_gd_iterations")
 
     def __del__(self):

@@ -173,17 +173,22 @@ def solve_gd(
 
     # ---- the hot loop (solver.py:252-355) on the device --------------------------------------------
     eng.begin(u_initial, target_load_factor, config)
-    n_done = 0
+    n_launched = 0
     st = None
     k = max(int(eng.GRAPH_ITERS), 1)
     poll = max(k, (CHECK_EVERY // k) * k)      # whole graph replays per poll (large meshes replay 20 iterations at a time)
-    while n_done < config.max_iterations:
-        chunk = min(poll, config.max_iterations - n_done)
-        eng.iterate(chunk)
+    while n_launched < config.max_iterations:
+        chunk = min(poll, config.max_iterations - n_launched)
+        # chained replays: a replay leaves the updates and the bookkeeping of its last iteration to the next replay's first
+        # iteration (HipEngine.iterate, defer_tail), so the state read here lags by that one iteration — the stop flag is all
+        # the loop needs; launches behind a stop are no-ops
+        eng.iterate(chunk, defer_tail=True)
+        n_launched += chunk
         st = eng.state()                       # one small D2H copy + sync per chunk
-        n_done = st.iter
         if st.done:
             break
+    eng.flush()                                # the pending tail (no-ops after a stop)
+    st = eng.state()
     n_iter = st.iter if st is not None else 0
     converged = bool(st.converged) if st is not None else False
     rows = eng.history(n_iter)

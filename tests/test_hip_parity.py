@@ -1096,6 +1096,43 @@ def test_graph_equals_eager_net_shapes(layers, we, wa, dim):
     _assert_history_equal(outs[0][-1], outs[1][-1])
 
 
+@pytest.mark.parametrize("n,max_it,tol,n_call,expect", [(250_000, 200, 0.0, 3 * 20 + 7, 67), (250_000, 200, 1e30, 60, 12),
+                                                       (250_000, 47, 0.0, 60, 47), (60_000, 200, 0.0, 4 * 10, 40)])
+def test_chained_replays_equal_plain_replays(n, max_it, tol, n_call, expect):
+    """iterate(defer_tail=True): a replay ends behind its last gradient-row reduction and the NEXT replay's first iteration
+    carries that iteration's parameter update, displacement update and bookkeeping (pf_graph_create_ex); flush() runs the one
+    pending tail.  Same bits as plain replays in u, theta, the Adam moments and the history: whole replays plus an eager
+    remainder, a stop raised inside the second replay's head (tolerance met at iteration 12), max_iterations reached inside a
+    replay, and the 10-iteration graphs of a smaller mesh."""
+    from bench import build_model
+    from pinn_fem_amd.engine import HipEngine
+    from pinn_fem_amd.fem.solver import SolverConfig
+    outs = []
+    for defer in (True, False):
+        model, mv, md, _ = build_model(n, "ex4")
+        cfg = SolverConfig(max_iterations=max_it, tolerance=tol, learning_rate_u=0.01, learning_rate_theta=5e-4)
+        eng = HipEngine(model, mv, md)
+        eng.begin(None, 0.1, cfg, want_history=True)
+        if defer:
+            assert eng.prepare_graph(chained=True)          # this problem has the chained form
+        eng.iterate(n_call, defer_tail=defer)
+        if defer and n_call % eng.GRAPH_ITERS == 0 and tol == 0.0 and max_it > n_call:
+            torch.cuda.synchronize()
+            assert eng.state().iter == n_call - 1           # the last iteration's bookkeeping is still pending
+        eng.flush()
+        torch.cuda.synchronize()
+        st = eng.state()
+        assert st.iter == expect and st.theta_half == 0
+        outs.append((eng.u.cpu().numpy().copy(), eng.theta.flat.cpu().numpy().copy(), eng.m_t.cpu().numpy().copy(),
+                     eng.v_t.cpu().numpy().copy(), eng.m_u.cpu().numpy().copy(), eng.history(expect).copy(),
+                     (st.done, st.converged)))
+        del eng
+    for a, b in zip(outs[0][:-2], outs[1][:-2]):
+        assert np.array_equal(a, b)
+    _assert_history_equal(outs[0][-2], outs[1][-2])         # (a plain replay's last displacement update is the stand-alone kernel)
+    assert outs[0][-1] == outs[1][-1]
+
+
 @pytest.mark.parametrize("max_it,tol,expect", [(40, 1e30, 12), (13, 0.0, 13), (15, 0.0, 15)])
 def test_graph_stop_in_mid_replay_equals_eager(max_it, tol, expect):
     """The iteration graph ping-pongs the displacement vector and the parameter state between two halves; a stop raised
