@@ -1320,7 +1320,9 @@ __device__ __forceinline__ void backward_phase(const pf_problem& P, int which, i
   const int partner = elder ? slot + hw : slot - hw;
   const int c_own = slot < ntasks_all ? (ntasks_all - 1 - slot) / per_round + 1 : 0;
   const int c_par = (hw > 0 && partner < ntasks_all) ? (ntasks_all - 1 - partner) / per_round + 1 : 0;
-  const int sh = (shift8 > 0 && hw > 0 && (waves & 1) == 0) ? (((elder ? c_par : c_own) * shift8 + 4) >> 3) : 0;
+  // (shift8 & 15: the handicap; a handicap can never exceed the younger wave's column)
+  const int sh = min(((shift8 & 15) > 0 && hw > 0 && (waves & 1) == 0) ? (((elder ? c_par : c_own) * (shift8 & 15) + 4) >> 3) : 0,
+                     elder ? c_par : c_own);
   const int n_mine = elder ? c_own + sh : c_own - sh;
   auto task_base = [&](int k) {                  // element base of the wave's k-th task; past its last one: the last element
     if (k < (elder ? c_own : n_mine)) return (k * per_round + slot) * 64;
