@@ -291,9 +291,10 @@ class HipEngine:
         _capi.check(self.lib.pf_reset(self._ref(), s), "pf_reset")
         _capi.check(self.lib.pf_pack_theta(self._ref(), s), "pf_pack_theta")
 
-    # iterations per captured hipGraph.  A replay ends with ~25 us of stand-alone kernels (parameter update, finalize) that the
-    # iterations inside it do not pay, so large meshes replay 20 at a time (the host polls the stop flag every 50
-    # anyway); small meshes keep 10 (a graph is captured per solve_gd call: capture time counts there).
+    # iterations per captured hipGraph.  A PLAIN replay ends with ~45 us of stand-alone kernels (parameter update, displacement
+    # update, finalize) that the iterations inside it do not pay, so large meshes replay 20 at a time (the host polls the stop
+    # flag every 50 anyway); small meshes keep 10 (a graph is captured per solve_gd call: capture time counts there).
+    # Chained replays (iterate(defer_tail=True)) pay that tail once per solve.
     # PINNFEM_GRAPH_ITERS overrides both (even numbers: the graph ping-pongs state between two halves).
     GRAPH_ITERS = 10
     GRAPH_ITERS_LARGE = 20
