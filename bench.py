@@ -491,6 +491,8 @@ def main():
                                "theta_update_in_next_forward (graph)": bool(fused & _capi.PF_FUSED_THETA_UPDATE),
                                "displacement_ping_pong (graph)": bool(fused & _capi.PF_FUSED_U_PINGPONG),
                                "displacement_update_in_next_forward (graph)": bool(fused & _capi.PF_FUSED_U_UPDATE),
+                               "replays_chained (a replay hands its last iteration's updates and bookkeeping to the next one)":
+                                   bool(world == 1 and all(getattr(eng, "_chain_graphs", {}).get(f) for f in (2, 3))),
                                "note": "a fused launch is booked on the first of its two kernel_ms slots"},
             "roofline": roof,
         }
